@@ -1,0 +1,154 @@
+/* greb_engine.h -- C ABI of the MI355X-native GREB time-integration engine.
+ *
+ * The reference (sieste/greb-climate-model) has no plugin / FFI interface: its routines are
+ * external Fortran procedures that talk through module globals.  The drop-in boundary is
+ * therefore the natural seam SURVEY.md 8(b) identifies -- the two time loops
+ *     src/greb.f90:325-362   (qflux_correction: flux-correction phase)
+ *     src/greb.f90:228-234   (greb_model: scenario phase, one time_loop call per step)
+ * and everything the reference hands across that seam today through modules mo_numerics /
+ * mo_physics / mo_diagnostics (src/greb.f90:32-158) is passed here explicitly.
+ *
+ * A thin Fortran host (greb_climate_model_amd/host/greb_host.f90, iso_c_binding) keeps the
+ * reference's CLI / namelist / input-file / output-record conventions and calls these entry
+ * points; INTEGRATION.md shows the bind(C) interface block.  Everything is plain C: pointers,
+ * ints, floats; no C++ or torch types.  All arrays are IEEE fp32 in the reference's own memory
+ * order (Fortran column-major == C [t][lat][lon], longitude fastest, latitude row 0 = south).
+ *
+ * Error convention: every entry returns int; 0 = ok, <0 = engine error (GREB_E_*), >0 = a
+ * hipError_t passed through.  greb_engine_last_error() gives a message.  Nothing throws or
+ * exits across the ABI.  An engine is used from one host thread at a time.
+ */
+#ifndef GREB_ENGINE_H
+#define GREB_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GREB_NSTEP_YR 730 /* ndays_yr*ndt_days, src/greb.f90:37-41 */
+#define GREB_NVAR_OUT 5   /* Tsurf, Tair, Tocean, q, albedo: src/greb.f90:978-982 */
+
+#define GREB_E_INVALID   (-1) /* bad argument / shape */
+#define GREB_E_NOGPU     (-2) /* no HIP device: the product path has no CPU fallback */
+#define GREB_E_STATE     (-3) /* call order (e.g. run before create) */
+#define GREB_E_UNSUPPORTED (-4)
+
+/* namelist group physics_par in declaration order (src/greb.f90:68-101,128-132),
+ * then co2_flux (:104), numerics (:51-53) and the two integer time steps (:38-39). */
+typedef struct greb_params {
+  float pi, sig, rho_ocean, rho_land, rho_air, cp_ocean, cp_land, cp_air, eps;
+  float d_ocean, d_land, d_air, ct_sens, da_ice, a_no_ice, a_cloud;
+  float Tl_ice1, Tl_ice2, To_ice1, To_ice2;
+  float co_turb, kappa, ce, cq_latent, cq_rain, z_air, z_vapor, r_qviwv;
+  float p_emi[10];
+  float co2_flux;
+  int32_t ipx, ipy;   /* 1-based diagnostic point, src/greb.f90:51-52,954 */
+  int32_t year0;
+  int32_t dt;         /* 43200 */
+  int32_t dt_crcl;    /* 1800  */
+} greb_params;
+
+/* Fill with the reference defaults (src/greb.f90:49-53,68-104). */
+void greb_params_default(greb_params* p);
+
+/* The reference's input set, host pointers (src/greb.f90:1073-1085). */
+typedef struct greb_fields {
+  const float* z_topo;   /* [ny][nx]       input/topography     */
+  const float* glacier;  /* [ny][nx]       input/glacier.masks  */
+  const float* sw_solar; /* [730][ny]      input/solar.radiation */
+  const float* tclim;    /* [730][ny][nx]  input/tsurf          */
+  const float* qclim;    /*                input/vapor          */
+  const float* uclim;    /*                input/zonal.wind     */
+  const float* vclim;    /*                input/meridional.wind */
+  const float* mldclim;  /*                input/ocean.mld      */
+  const float* cldclim;  /*                input/cloud.cover    */
+  const float* swetclim; /*                input/soil.moisture  */
+} greb_fields;
+
+/* Per-member physics overrides for perturbed-physics ensembles (BASELINE config 5).
+ * A member is what a separate `ens_id` process is in the reference (src/greb.f90:153,1064-1068).
+ * NaN in a slot = keep the engine-wide greb_params value. */
+typedef struct greb_member_overrides {
+  float da_ice, a_no_ice, a_cloud, kappa;
+} greb_member_overrides;
+
+/* engine flags */
+#define GREB_F_STRICT 1u /* reference operation order, IEEE division, no FMA contraction
+                            (bit-exact stencils; default is the restructured fast arithmetic) */
+
+typedef struct greb_engine greb_engine;
+
+/* Create an engine for n_members ensemble members on HIP device `device`.
+ * Copies the inputs to HBM, computes the derived fields of greb_model's preamble
+ * (src/greb.f90:176-216) and Toclim (src/greb.f90:1088-1094) and sets every member's
+ * state to the initial state (src/greb.f90:194-197).  overrides may be NULL. */
+int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* f, int n_members,
+                       const greb_member_overrides* overrides, int device, unsigned flags,
+                       greb_engine** out);
+
+/* qflux_correction (src/greb.f90:311-364): `years`*730 steps at co2_flux; leaves the
+ * correction arrays, cap_surf and the spun-up state in the engine.
+ * yearly may be NULL, else [n_members][years][2] = {global-mean Tsurf, Tsurf(ipx,ipy)} in
+ * deg C as printed at src/greb.f90:954. */
+int greb_engine_flux_correction(greb_engine* e, int years, float* yearly);
+
+/* Scenario run (src/greb.f90:226-234 + time_loop :239-274): `years`*730 steps.
+ *   co2_ppm : [n_members][years]   annual CO2, already padded (src/greb.f90:1053-1061)
+ *   monthly : [n_members][years][12][5][ny][nx]  monthly means in file-record order
+ *             (src/greb.f90:978-982); host memory unless GREB_RUN_DEVICE_OUT
+ *   yearly  : [n_members][years][2] as above (may be NULL)
+ * May be called repeatedly; the model clock (it, year, month accumulators) continues. */
+#define GREB_RUN_DEVICE_OUT 1u /* `monthly` is a device pointer (e.g. for an RCCL gather) */
+int greb_engine_run(greb_engine* e, int years, const float* co2_ppm, float* monthly, float* yearly,
+                    unsigned run_flags);
+
+/* Flux-correction cache: TF/qF/ToF_correct [3][730][ny][nx] + cap_surf +
+ * the four state fields Ts,Ta,To,q [5][ny][nx] of one member. */
+int greb_engine_get_corrections(greb_engine* e, int member, float* corr, float* state5);
+int greb_engine_set_corrections(greb_engine* e, int member, const float* corr, const float* state5);
+
+/* Current state of one member: Ts, Ta, To, q, cap_surf [5][ny][nx]. */
+int greb_engine_get_state(greb_engine* e, int member, float* state5);
+
+const char* greb_engine_last_error(const greb_engine* e);
+int greb_engine_destroy(greb_engine* e);
+
+/* Device + build info as a static JSON string (CU count, clocks, arch). */
+const char* greb_device_info(int device);
+
+/* ---- single-routine entry points over a batch dimension (tests + roofline bench) --------
+ * Mirrors of the reference routines' signatures with a leading batch count; all pointers are
+ * HOST pointers unless the name ends in _dev.  `p` supplies pi/kappa/dt_crcl.
+ *   diffusion  src/greb.f90:556-723   dX = wz*(dTx+dTy)
+ *   advection  src/greb.f90:726-915   winds u,v are the raw climatology slice (sign split inside)
+ *   circulation src/greb.f90:528-553  24 sub-steps of X += diffusion + advection
+ * Shapes: T1, wz, dX, u, v : [batch][ny][nx].  strict: 0/1 as GREB_F_STRICT. */
+int greb_diffusion_batched(const greb_params* p, int nx, int ny, int batch, const float* T1,
+                           const float* wz, float* dX, int strict, int device);
+int greb_advection_batched(const greb_params* p, int nx, int ny, int batch, const float* T1,
+                           const float* wz, const float* u, const float* v, float* dX, int strict,
+                           int device);
+int greb_circulation_batched(const greb_params* p, int nx, int ny, int batch, const float* X,
+                             const float* wz, const float* u, const float* v, float* dX, int strict,
+                             int device);
+/* Device-pointer form of the diffusion sweep for the HBM-roofline measurement: launches
+ * `sweeps` back-to-back sweeps on `stream` (a hipStream_t, may be NULL) and returns without
+ * synchronising.  Algorithmic traffic = 12 B/point/member-sweep. */
+int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, const float* T1_dev,
+                               const float* wz_dev, float* dX_dev, int strict, int sweeps,
+                               void* stream);
+
+/* Point physics of one step for a batch of columns sets (tests): SWradiation :367-403,
+ * LWradiation :407-434, hydro :438-469, deep_ocean :495-525, seaice :472-492 evaluated by the
+ * same device functions the engine uses.  in  : Ts,Ta,To,q,cap_surf [5][ny][nx]
+ *                                          out : 15 fields [15][ny][nx] in the order
+ * albedo, sw, LW_surf, LWair_down, em, Q_sens, Q_lat, Q_lat_air, dq_eva, dq_rain, dT_ocean, dTo,
+ * cap_surf_new(seaice(Ts)), 0, 0.   ityr is 1-based. */
+int greb_engine_point_physics(greb_engine* e, int ityr, float co2, const float* in5, float* out15);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GREB_ENGINE_H */

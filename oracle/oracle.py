@@ -1,0 +1,317 @@
+"""ctypes wrappers for the two CPU checkers.  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+  Oracle  -> oracle/liboracle_greb.so   (the C restatement, oracle/greb_oracle.c)
+  RefLib  -> oracle/_ref/libgreb_ref.so (the reference Fortran itself, compiled by oracle/Makefile;
+                                         per-routine calls + module globals)
+  run_reference_binary -> oracle/_ref/greb_ref  (whole program, reads input/ + namelist, writes output/)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+
+from greb_climate_model_amd import abi, workload
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle_greb.so")
+REF_SO = os.path.join(HERE, "_ref", "libgreb_ref.so")
+REF_BIN = os.path.join(HERE, "_ref", "greb_ref")
+NT = 730
+fp = abi.fptr
+
+
+def build(ref: bool = True) -> None:
+    """make oracle (+ ref when /root/reference is present)."""
+    subprocess.run(["make", "-s", "-C", HERE, "oracle"] + (["ref"] if ref else []), check=True)
+
+
+class _Grid(C.Structure):
+    _fields_ = [(n, abi.c_float_p) for n in ("dxlat", "dif_ccx", "adv_ccx", "dif_ccx2", "adv_ccx2")] + \
+               [(n, C.POINTER(C.c_int)) for n in ("dif_time2", "adv_time2", "subcycled")] + \
+               [("dif_ccy", C.c_float), ("adv_ccy", C.c_float)]
+
+
+class Oracle:
+    """The C restatement (one member)."""
+
+    def __init__(self, inp: workload.Inputs, params: abi.GrebParams | None = None):
+        if not os.path.exists(ORACLE_SO):
+            build(ref=False)
+        self.lib = L = C.CDLL(ORACLE_SO)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_get_grid.restype = C.POINTER(_Grid)
+        L.oracle_field.restype = abi.c_float_p
+        self.params = params or abi.default_params()
+        self.nx, self.ny = inp.nx, inp.ny
+        self.np = self.nx * self.ny
+        fields, self._keep = abi.make_fields(inp)
+        self.h = C.c_void_p(L.oracle_create(C.byref(self.params), self.nx, self.ny, C.byref(fields)))
+
+    def close(self):
+        if self.h:
+            self.lib.oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    def _f(self):
+        return np.empty((self.ny, self.nx), np.float32)
+
+    def grid(self) -> dict:
+        g = self.lib.oracle_get_grid(self.h).contents
+        out = {}
+        for n in ("dxlat", "dif_ccx", "adv_ccx", "dif_ccx2", "adv_ccx2", "dif_time2", "adv_time2", "subcycled"):
+            out[n] = np.ctypeslib.as_array(getattr(g, n), shape=(self.ny,)).copy()
+        out["dif_ccy"], out["adv_ccy"] = np.float32(g.dif_ccy), np.float32(g.adv_ccy)
+        return out
+
+    def field(self, which: int, nt: int = 1) -> np.ndarray:
+        """View (not copy) of an oracle array: 0 Ts 1 Ta 2 To 3 q 4 cap_surf 5 wz_air 6 wz_vapor
+        7 z_ocean 8 Toclim ; 10/11/12 TF/qF/ToF_correct (nt=730)."""
+        p = self.lib.oracle_field(self.h, which)
+        shape = (self.ny, self.nx) if nt == 1 else (nt, self.ny, self.nx)
+        return np.ctypeslib.as_array(p, shape=shape)
+
+    # ---- routines
+    def diffusion(self, T1, wz):
+        T1, wz = np.ascontiguousarray(T1, np.float32), np.ascontiguousarray(wz, np.float32)
+        out = self._f()
+        self.lib.oracle_diffusion(self.h, fp(T1), fp(out), fp(wz))
+        return out
+
+    def advection(self, T1, wz, ityr=None, u=None, v=None):
+        T1, wz = np.ascontiguousarray(T1, np.float32), np.ascontiguousarray(wz, np.float32)
+        out = self._f()
+        if u is None:
+            self.lib.oracle_advection(self.h, int(ityr), fp(T1), fp(out), fp(wz))
+        else:
+            u, v = np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32)
+            self.lib.oracle_advection_uv(self.h, fp(u), fp(v), fp(T1), fp(out), fp(wz))
+        return out
+
+    def circulation(self, X, wz, ityr=None, u=None, v=None):
+        X, wz = np.ascontiguousarray(X, np.float32), np.ascontiguousarray(wz, np.float32)
+        out = self._f()
+        if u is None:
+            self.lib.oracle_circulation(self.h, int(ityr), fp(X), fp(out), fp(wz))
+        else:
+            u, v = np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32)
+            self.lib.oracle_circulation_uv(self.h, fp(u), fp(v), fp(X), fp(out), fp(wz))
+        return out
+
+    def swradiation(self, ityr, Ts):
+        Ts = np.ascontiguousarray(Ts, np.float32)
+        sw, alb = self._f(), self._f()
+        self.lib.oracle_swradiation(self.h, int(ityr), fp(Ts), fp(sw), fp(alb))
+        return sw, alb
+
+    def lwradiation(self, ityr, Ts, Ta, q, co2):
+        Ts, Ta, q = (np.ascontiguousarray(a, np.float32) for a in (Ts, Ta, q))
+        o = [self._f() for _ in range(4)]
+        self.lib.oracle_lwradiation(self.h, int(ityr), fp(Ts), fp(Ta), fp(q), C.c_float(co2), *[fp(a) for a in o])
+        return tuple(o)  # LWsurf, LWair_up, LWair_down, em
+
+    def hydro(self, ityr, Ts, q):
+        Ts, q = np.ascontiguousarray(Ts, np.float32), np.ascontiguousarray(q, np.float32)
+        o = [self._f() for _ in range(4)]
+        self.lib.oracle_hydro(self.h, int(ityr), fp(Ts), fp(q), *[fp(a) for a in o])
+        return tuple(o)  # Qlat, Qlat_air, dq_eva, dq_rain
+
+    def seaice(self, ityr, Ts):
+        Ts = np.ascontiguousarray(Ts, np.float32)
+        self.lib.oracle_seaice(self.h, int(ityr), fp(Ts))
+        return self.field(4).copy()
+
+    def deep_ocean(self, ityr, Ts, To):
+        Ts, To = np.ascontiguousarray(Ts, np.float32), np.ascontiguousarray(To, np.float32)
+        a, b = self._f(), self._f()
+        self.lib.oracle_deep_ocean(self.h, int(ityr), fp(Ts), fp(To), fp(a), fp(b))
+        return a, b  # dT_ocean, dTo
+
+    def flux_correction(self, years):
+        yearly = np.zeros((max(years, 1), 2), np.float32)
+        self.lib.oracle_flux_correction(self.h, int(years), fp(yearly))
+        return yearly[:years]
+
+    def run(self, years, co2_ppm):
+        co2 = np.ascontiguousarray(np.broadcast_to(np.asarray(co2_ppm, np.float32), (years,)))
+        monthly = np.zeros((years, 12, 5, self.ny, self.nx), np.float32)
+        yearly = np.zeros((years, 2), np.float32)
+        self.lib.oracle_run(self.h, int(years), fp(co2), fp(monthly), fp(yearly))
+        return monthly, yearly
+
+    def state5(self):
+        return np.stack([self.field(i).copy() for i in range(5)])
+
+
+# --------------------------------------------------------------------------------------------
+class RefLib:
+    """The reference's own subroutines, called one at a time (build container only)."""
+
+    G3 = ("tclim", "uclim", "vclim", "qclim", "mldclim", "toclim", "cldclim", "tf_correct", "qf_correct",
+          "tof_correct", "swetclim", "dtrad", "uclim_m", "uclim_p", "vclim_m", "vclim_p")
+
+    def __init__(self, inp: workload.Inputs, oracle: Oracle):
+        """Module state is set from `inp` plus the derived fields of greb_model's preamble
+        (src/greb.f90:176-216), which are taken from `oracle` (they are inputs here; the
+        preamble itself is pinned by the whole-run comparison)."""
+        assert (inp.nx, inp.ny) == (96, 48), "reference grid is compile-time 96x48 (src/greb.f90:36)"
+        self.lib = L = C.CDLL(REF_SO)
+        self.nx, self.ny, self.np = 96, 48, 96 * 48
+        self.inp = inp
+        self.g2("z_topo")[:] = inp.z_topo
+        self.g2("glacier")[:] = inp.glacier
+        self.g("sw_solar", (NT, 48))[:] = inp.sw_solar
+        for name, src in (("tclim", inp.tclim), ("uclim", inp.uclim), ("vclim", inp.vclim), ("qclim", inp.qclim),
+                          ("mldclim", inp.mldclim), ("cldclim", inp.cldclim), ("swetclim", inp.swetclim)):
+            self.g3(name)[:] = src
+        self.g3("toclim")[:] = oracle.field(8)[None]
+        self.g3("dtrad")[:] = np.float32(-0.16) * inp.tclim - np.float32(5.0)  # src/greb.f90:176
+        u, v = inp.uclim, inp.vclim
+        self.g3("uclim_m")[:] = np.where(u >= 0, u, np.float32(0))  # :203-209
+        self.g3("uclim_p")[:] = np.where(u >= 0, np.float32(0), u)
+        self.g3("vclim_m")[:] = np.where(v >= 0, v, np.float32(0))  # :210-216
+        self.g3("vclim_p")[:] = np.where(v >= 0, np.float32(0), v)
+        self.g2("z_ocean")[:] = oracle.field(7)
+        self.g2("wz_air")[:] = oracle.field(5)
+        self.g2("wz_vapor")[:] = oracle.field(6)
+        self.g2("cap_surf")[:] = oracle.field(4)
+        p = oracle.params
+        for n, sym in (("cap_ocean", p.cp_ocean * 1.0), ):
+            pass
+        f32 = np.float32
+        self.scalar("cap_ocean").value = float(f32(p.cp_ocean) * f32(p.rho_ocean))          # :186
+        self.scalar("cap_land").value = float(f32(p.cp_land) * f32(p.rho_land) * f32(p.d_land))  # :187
+        self.scalar("cap_air").value = float(f32(p.cp_air) * f32(p.rho_air) * f32(p.d_air))  # :188
+
+    # module-global accessors (flang mangling _QMmo_physicsE<lowercase name>)
+    def g(self, name, shape, mod="mo_physics"):
+        n = int(np.prod(shape))
+        arr = (C.c_float * n).in_dll(self.lib, f"_QM{mod}E{name}")
+        return np.ctypeslib.as_array(arr).reshape(shape)
+
+    def g2(self, name, mod="mo_physics"):
+        return self.g(name, (48, 96), mod)
+
+    def g3(self, name):
+        return self.g(name, (NT, 48, 96))
+
+    def scalar(self, name, ctype=C.c_float, mod="mo_physics"):
+        return ctype.in_dll(self.lib, f"_QM{mod}E{name}")
+
+    def set_ityr(self, ityr):
+        self.scalar("ityr", C.c_int).value = int(ityr)
+
+    def params_from_module(self) -> dict:
+        out = {n: self.scalar(n.lower()).value for n in abi.GrebParams.PHYSICS_NAMES}
+        out["p_emi"] = list((C.c_float * 10).in_dll(self.lib, "_QMmo_physicsEp_emi"))
+        out["co2_flux"] = self.scalar("co2_flux").value
+        return out
+
+    def _f(self):
+        return np.empty((48, 96), np.float32)
+
+    def diffusion(self, T1, wz):
+        T1, wz = np.ascontiguousarray(T1, np.float32), np.ascontiguousarray(wz, np.float32)
+        out, h = self._f(), C.c_float(0)
+        self.lib.diffusion_(fp(T1), fp(out), C.byref(h), fp(wz))
+        return out
+
+    def advection(self, ityr, T1, wz):
+        self.set_ityr(ityr)
+        T1, wz = np.ascontiguousarray(T1, np.float32), np.ascontiguousarray(wz, np.float32)
+        out, h = self._f(), C.c_float(0)
+        self.lib.advection_(fp(T1), fp(out), C.byref(h), fp(wz))
+        return out
+
+    def circulation(self, ityr, X, wz):
+        self.set_ityr(ityr)
+        X, wz = np.ascontiguousarray(X, np.float32), np.ascontiguousarray(wz, np.float32)
+        out, h = self._f(), C.c_float(0)
+        self.lib.circulation_(fp(X), fp(out), C.byref(h), fp(wz))
+        return out
+
+    def swradiation(self, ityr, Ts):
+        self.set_ityr(ityr)
+        Ts = np.ascontiguousarray(Ts, np.float32)
+        sw, alb = self._f(), self._f()
+        self.lib.swradiation_(fp(Ts), fp(sw), fp(alb))
+        return sw, alb
+
+    def lwradiation(self, ityr, Ts, Ta, q, co2):
+        self.set_ityr(ityr)
+        Ts, Ta, q = (np.ascontiguousarray(a, np.float32) for a in (Ts, Ta, q))
+        LWsurf, up, down, em = (self._f() for _ in range(4))
+        c = C.c_float(co2)
+        self.lib.lwradiation_(fp(Ts), fp(Ta), fp(q), C.byref(c), fp(LWsurf), fp(up), fp(down), fp(em))
+        return LWsurf, up, down, em
+
+    def hydro(self, ityr, Ts, q):
+        self.set_ityr(ityr)
+        Ts, q = np.ascontiguousarray(Ts, np.float32), np.ascontiguousarray(q, np.float32)
+        o = [self._f() for _ in range(4)]
+        self.lib.hydro_(fp(Ts), fp(q), *[fp(a) for a in o])
+        return tuple(o)
+
+    def seaice(self, ityr, Ts, cap_surf_in):
+        self.set_ityr(ityr)
+        self.g2("cap_surf")[:] = cap_surf_in
+        Ts = np.ascontiguousarray(Ts, np.float32)
+        self.lib.seaice_(fp(Ts))
+        return self.g2("cap_surf").copy()
+
+    def deep_ocean(self, ityr, Ts, To):
+        self.set_ityr(ityr)
+        Ts, To = np.ascontiguousarray(Ts, np.float32), np.ascontiguousarray(To, np.float32)
+        a, b = self._f(), self._f()
+        self.lib.deep_ocean_(fp(Ts), fp(To), fp(a), fp(b))
+        return a, b
+
+
+def run_reference_binary(inp: workload.Inputs, time_flux: int, time_scnr: int, co2_ppm=(680.0,),
+                         ipx: int = 95, ipy: int = 38, workdir: str | None = None, physics=None,
+                         keep: bool = False):
+    """Run oracle/_ref/greb_ref exactly as a user runs ./greb (src/greb.f90:996-1098).
+    Returns (monthly [months][5][ny][nx], stdout text, wall seconds)."""
+    import time
+    if not os.path.exists(REF_BIN):
+        raise FileNotFoundError(REF_BIN + " (build with `make -C oracle ref` in the build container)")
+    wd = workdir or tempfile.mkdtemp(prefix="greb_ref_")
+    try:
+        inp.write_input_dir(os.path.join(wd, "input"))
+        os.makedirs(os.path.join(wd, "output"), exist_ok=True)
+        workload.write_namelist(os.path.join(wd, "namelist"), time_flux, time_scnr, co2_ppm, ipx, ipy,
+                                physics=physics)
+        t0 = time.time()
+        r = subprocess.run([REF_BIN], cwd=wd, capture_output=True, text=True, check=True)
+        wall = time.time() - t0
+        monthly = workload.read_greb(os.path.join(wd, "output", "scenario"), inp.nx, inp.ny)
+        return monthly, r.stdout, wall
+    finally:
+        if not keep and workdir is None:
+            shutil.rmtree(wd, ignore_errors=True)
+
+
+def parse_ref_stdout(text: str) -> np.ndarray:
+    """The `year co2 gmean tpoint` lines (src/greb.f90:954) -> [n][4] float array."""
+    rows = []
+    for line in text.splitlines():
+        parts = line.split()
+        if len(parts) == 4:
+            try:
+                rows.append([float(x) for x in parts])
+            except ValueError:
+                pass
+    return np.asarray(rows, np.float64)
