@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- simulated-years/s of the GREB time-integration engine on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--members M] [--strict]
+
+A "step" is ONE SIMULATED MODEL-YEAR (730 model steps = 35 040 diffusion + 35 040 advection
+sweeps per member) for every ensemble member resident on the GPU.  Members are independent
+96x48 GREB integrations that differ in their CO2 level (BASELINE config 4's sweep, 280-1120
+ppm), M per GPU (default 512: the single grid occupies one CU, so a GPU is only full with
+hundreds of members -- SURVEY.md 0.6).  value = members x years / wall over all ranks
+(weak scaling: M per GPU fixed).  At N>1 the monthly means of every member are gathered to
+rank 0 over RCCL inside the timed region (north_star's only collective).
+
+Extra objects on the JSON line:
+  roofline      the standalone batched diffusion kernel (the kernel BASELINE's second metric is
+                defined on): algorithmic 12 B/point/sweep over its HIP-event-timed launches
+  cpu_baseline  the reference Fortran itself (oracle/_ref/greb_ref, built from
+                /root/reference in the build container; "reference") or, if that binary is
+                absent, the C restatement ("port"), 1 core, bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--members", type=int, default=512, help="ensemble members per GPU")
+    ap.add_argument("--strict", action="store_true", help="reference operation order (bit-exact stencils)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-batch", type=int, default=16384)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from greb_climate_model_amd import engine, ensemble, workload
+    K, W, M = args.steps, args.warmup, args.members
+    inp = workload.make_inputs()
+    params = engine.params_default()
+    params.ipx, params.ipy = 95, 38
+
+    # ---------------- ensemble: global member g = rank*M + i, CO2 swept over 280..1120 ppm
+    levels = ensemble.co2_sweep(world * M)[rank * M:(rank + 1) * M]
+    eng = engine.Engine(inp, params, n_members=M, device=local_rank, strict=args.strict)
+    eng.flux_correction(1)  # shared by all members (same physics): one member integrated, state broadcast
+    np_ = eng.np
+    monthly = torch.empty((M, K, 12, 5, np_), dtype=torch.float32, device="cuda")
+    if W > 0:
+        wbuf = torch.empty((M, W, 12, 5, np_), dtype=torch.float32, device="cuda")
+        eng.run(W, np.repeat(levels[:, None], W, 1), monthly_dev_ptr=wbuf.data_ptr())
+        del wbuf
+    gathered = None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty_like(monthly) for _ in range(world)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    eng.run(K, np.repeat(levels[:, None], K, 1), monthly_dev_ptr=monthly.data_ptr())
+    if world > 1:
+        dist.gather(monthly, gathered, dst=0)  # RCCL over xGMI: the monthly-mean gather
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    value = world * M * K / dt
+
+    finite = bool(torch.isfinite(monthly).all().item())
+    tmean = float(monthly[:, -1, :, 0].mean().item())
+
+    extra = {}
+    if rank == 0:
+        # single-member latency figure (one member = one CU busy), for the configs with 1 member/GPU
+        e1 = engine.Engine(inp, params, n_members=1, device=local_rank, strict=args.strict)
+        e1.flux_correction(1)
+        t1 = time.perf_counter(); e1.run(2, 680.0); t1 = time.perf_counter() - t1
+        extra["single_member_years_per_s"] = round(2 / t1, 2)
+        e1.close()
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        roof = roofline_diffusion(torch, engine, params, args.roofline_batch, args.strict)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(inp)
+
+    if rank == 0:
+        out = {
+            "metric": "simulated-years/sec at 96x48 grid (ensemble aggregate); diffusion HBM GB/s vs roofline",
+            "value": round(value, 2), "unit": "simulated-years/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(1e3 * dt / K, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"96x48 GREB ensemble, {M} members/GPU x {world} GPU, CO2 sweep 280-1120 ppm, "
+                                   f"{K} scenario years after 1 flux-correction year, dt=12h, dt_crcl=0.5h",
+                       "members_per_gpu": M, "arithmetic": "strict" if args.strict else "fast",
+                       "gather": "rccl gather of monthly means to rank 0" if world > 1 else "none (1 GPU)"},
+            "years_per_s_per_gpu": round(value / world, 2),
+            "finite": finite, "last_year_mean_tsurf_K": round(tmean, 3),
+            "device": engine.device_info(local_rank),
+        }
+        out.update(extra)
+        if roof is not None:
+            out["roofline"] = roof
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline_diffusion(torch, engine, params, batch, strict, sweeps=20):
+    """Standalone batched diffusion sweep (src/greb.f90:556-723) timed with HIP events on the
+    stream it is launched on.  Algorithmic bytes = 12 B/point/field-sweep (SURVEY.md 8d):
+    read T1, read wz, write dX.  batch*3*18 KB >= 0.9 GB so the 256 MB Infinity Cache cannot
+    serve it."""
+    nx, ny = 96, 48
+    n = batch * nx * ny
+    g = torch.Generator(device="cuda").manual_seed(1)
+    T1 = 250.0 + 50.0 * torch.rand(n, device="cuda", generator=g)
+    wz = 0.3 + 0.7 * torch.rand(n, device="cuda", generator=g)
+    dX = torch.empty(n, device="cuda")
+    stream = torch.cuda.current_stream()
+    engine.diffusion_dev(params, nx, ny, batch, T1.data_ptr(), wz.data_ptr(), dX.data_ptr(), strict, 3, stream.cuda_stream)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(sweeps + 1)]
+    ev[0].record(stream)
+    for i in range(sweeps):
+        engine.diffusion_dev(params, nx, ny, batch, T1.data_ptr(), wz.data_ptr(), dX.data_ptr(), strict, 1, stream.cuda_stream)
+        ev[i + 1].record(stream)
+    torch.cuda.synchronize()
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(sweeps)]
+    avg = float(np.mean(ms)) * 1e-3
+    # measured copy bandwidth of this box as the second denominator
+    a = torch.empty(n, device="cuda");
+    for _ in range(3): a.copy_(T1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(10): a.copy_(T1)
+    e1.record(stream); torch.cuda.synchronize()
+    copy_gbs = 10 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    algo = 12.0 * n
+    achieved = algo / avg / 1e9
+    return {"kernel": "sweep_kernel<diffusion>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
+            "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(avg * 1e3, 4), "batch": batch,
+            "min_launch_ms": round(float(np.min(ms)), 4), "measured_copy_GBps": round(copy_gbs, 1),
+            "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
+
+
+def cpu_baseline(inp):
+    """The reference's own loop on this box's host cores: 1 core (it is single-threaded,
+    Makefile:12), bounded sample = 1 flux-correction year + 9 scenario years of the same workload."""
+    import platform
+    from oracle import oracle as O  # checker/baseline only -- never on the product path
+    cpu = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    ncores = os.cpu_count()
+    if os.path.exists(O.REF_BIN):
+        mon, out, wall = O.run_reference_binary(inp, 1, 9)
+        # wall includes reading 94 MB of inputs; the model itself is > 95 % of it
+        return {"value": round(10 / wall, 3), "unit": "simulated-years/s", "cores": 1, "kind": "reference",
+                "sample": "reference Fortran (amdflang -O2) 1+9 model-years, 96x48, same synthetic inputs, 1 member",
+                "host_cpu": cpu, "host_cores_available": ncores}
+    O.build(ref=False)
+    o = O.Oracle(inp)
+    t = time.perf_counter(); o.flux_correction(1); o.run(9, 680.0); wall = time.perf_counter() - t
+    return {"value": round(10 / wall, 3), "unit": "simulated-years/s", "cores": 1, "kind": "port",
+            "sample": "C restatement (gcc -O3 -ffp-contract=off) 1+9 model-years, 96x48, same synthetic inputs, 1 member",
+            "host_cpu": cpu, "host_cores_available": ncores}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""Build libgreb_hip.so (the C-ABI engine) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
+git-ignored but travels to the GPU box with the snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libgreb_hip.so")
+SOURCES = ["greb_engine.cpp", "greb_kernels.hip"]
+HEADERS = ["greb_device.h", "greb_kernels.h", os.path.join(ROOT, "include", "greb_engine.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+               "-I" + os.path.join(ROOT, "include")]
+
+
+def hipcc() -> str:
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), *HIPCC_FLAGS, "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+def build_host(verbose: bool = False) -> str | None:
+    """The thin Fortran host (greb_host.f90, iso_c_binding) -> greb_climate_model_amd/greb_host.
+    Returns None when no Fortran compiler is present."""
+    fc = shutil.which("amdflang") or ("/opt/rocm/bin/amdflang" if os.path.exists("/opt/rocm/bin/amdflang") else None)
+    src = os.path.join(PKG, "host", "greb_host.f90")
+    if fc is None or not os.path.exists(src):
+        return None
+    out = os.path.join(PKG, "greb_host")
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return out
+    moddir = os.path.join(PKG, "host", "_mod")
+    os.makedirs(moddir, exist_ok=True)
+    cmd = [fc, "-O2", "-module-dir", moddir, "-o", out, src, "-L" + PKG, "-lgreb_hip", "-Wl,-rpath," + PKG,
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))
+    print(build_host(verbose=True))

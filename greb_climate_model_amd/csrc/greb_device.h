@@ -1,0 +1,337 @@
+// greb_device.h -- device-side arithmetic of the GREB hot path for gfx950 (CDNA4), wave64.
+//
+// Two arithmetic flavours of every stencil piece:
+//   STRICT : the reference's expression trees verbatim (src/greb.f90:585-721, 756-913), IEEE
+//            division, FMA contraction off  -> bit-identical to the reference/oracle.
+//   FAST   : algebraically restructured "edge-flux" form.  With e_m = T(m+1)-T(m),
+//            P+_m = w(m+1)*e_m, P-_m = w(m)*e_m, the reference's 7-point diffusion sum
+//            (src/greb.f90:595-600) collapses to
+//                S_j = 6(P+_j - P-_{j-1}) + 3(P+_{j+1} - P-_{j-2}) + (P+_{j+2} - P-_{j-3})
+//            and both advection stencils (:802-806, :845-851) are linear in the same P's;
+//            divisions become multiplications by precomputed reciprocals; FMA allowed.
+//            Only the increments change (relative 1e-7); the state update keeps the reference's
+//            two roundings X = (X + dX_diffuse) + dX_advec (src/greb.f90:549).
+//
+// Data is processed in "quads": 4 consecutive longitudes (one 16-byte LDS/HBM access).  A quad
+// window t[12] holds longitudes 4(q-1) .. 4(q+1)+3 with periodic wrap; the quad's own points are
+// t[4..7].
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace greb {
+
+constexpr int kMaxNy = 192;
+
+// Per-row tables of diffusion/advection (src/greb.f90:578-582, 652-654, 749-753, 838-840),
+// computed on the host in fp32 exactly as the reference does; one set per distinct kappa.
+struct RowTables {
+  float dif_ccy, adv_ccy;
+  float dif_ccx[kMaxNy], adv_ccx[kMaxNy];   // full-row branch
+  float dif_ccx2[kMaxNy], adv_ccx2[kMaxNy]; // sub-cycled branch
+  int dif_time2[kMaxNy], adv_time2[kMaxNy];
+  int subcycled[kMaxNy];                    // !(dxlat(k) > 2.5e5)
+};
+
+struct f4 {
+  float v[4];
+};
+
+__device__ __forceinline__ f4 ld4(const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  return f4{{a.x, a.y, a.z, a.w}};
+}
+__device__ __forceinline__ void st4(float* p, const f4& a) {
+  *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+
+// window of 12 longitudes around quad q of a row (periodic, src/greb.f90:594,602,610,...)
+__device__ __forceinline__ void load_window(const float* row, int q, int nq, float t[12]) {
+  const int qm = (q == 0) ? nq - 1 : q - 1;
+  const int qp = (q == nq - 1) ? 0 : q + 1;
+  const f4 a = ld4(row + 4 * qm), b = ld4(row + 4 * q), c = ld4(row + 4 * qp);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { t[i] = a.v[i]; t[4 + i] = b.v[i]; t[8 + i] = c.v[i]; }
+}
+
+__device__ __forceinline__ float split_m(float u) { return u >= 0.0f ? u : 0.0f; } // src/greb.f90:203-205
+__device__ __forceinline__ float split_p(float u) { return u >= 0.0f ? 0.0f : u; } // src/greb.f90:206-208
+
+// ============================================================================================
+// STRICT pieces (reference expression order)
+// ============================================================================================
+
+// 7-point sum of src/greb.f90:595-600 for window index c (4..7)
+__device__ __forceinline__ float dif_S_strict(const float* T, const float* w, int c) {
+#pragma clang fp contract(off)
+  return 10.f * (w[c - 1] * (T[c - 1] - T[c]) + w[c + 1] * (T[c + 1] - T[c]))
+         + 4.f * (w[c - 2] * (T[c - 2] - T[c - 1]) + w[c - 1] * (T[c] - T[c - 1]))
+         + 4.f * (w[c + 1] * (T[c] - T[c + 1]) + w[c + 2] * (T[c + 2] - T[c + 1]))
+         + (w[c - 3] * (T[c - 3] - T[c - 2]) + w[c - 2] * (T[c - 1] - T[c - 2]))
+         + (w[c + 2] * (T[c + 1] - T[c + 2]) + w[c + 3] * (T[c + 3] - T[c + 2]));
+}
+
+// one longitudinal diffusion increment: cc*S/20  (:595-600 with ccx, :659-664 with ccx2)
+__device__ __forceinline__ void dif_lon_strict(const float T[12], const float w[12], float cc, float d[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d[i] = cc * dif_S_strict(T, w, 4 + i) / 20.f;
+}
+
+// src/greb.f90:802-806: full-row advection, window index c
+__device__ __forceinline__ void adv_lon_full_strict(const float T[12], const float w[12], const float u[4],
+                                                    float ccx, float d[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 + i;
+    d[i] = ccx * (-split_m(u[i]) * (w[c - 1] * (T[c] - T[c - 1]) + w[c - 2] * (T[c] - T[c - 2]))
+                  + split_p(u[i]) * (w[c + 1] * (T[c] - T[c + 1]) + w[c + 2] * (T[c] - T[c + 2])))
+           / 3.f;
+  }
+}
+
+// src/greb.f90:845-851 (+ the :881 index bug for j = xdim-2): sub-cycled advection increment
+__device__ __forceinline__ void adv_lon_sub_strict(const float T[12], const float w[12], const float u[4],
+                                                   float ccx2, bool last_quad, float d[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 + i;
+    const int p1 = c + 1;
+    // :881  jp2 = xdim-1 (1-based) for j = xdim-2: the "+2" neighbour aliases the "+1" one
+    const int p2 = (last_quad && i == 1) ? c + 1 : c + 2;
+    const int p3 = c + 3;
+    d[i] = ccx2 * (-split_m(u[i]) * (10.f * w[c - 1] * (T[c] - T[c - 1])
+                                     + 4.f * w[c - 2] * (T[c - 1] - T[c - 2])
+                                     + w[c - 3] * (T[c - 2] - T[c - 3]))
+                   + split_p(u[i]) * (10.f * w[p1] * (T[c] - T[p1])
+                                      + 4.f * w[p2] * (T[p1] - T[p2])
+                                      + w[p3] * (T[p2] - T[p3])))
+           / 20.f;
+  }
+}
+
+// clamp + accumulate of the sub-cycle loops (:715-716, :907-908)
+__device__ __forceinline__ void clamp_add(float T1h[4], float d[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (d[i] <= -T1h[i]) d[i] = -0.9f * T1h[i];
+    T1h[i] = T1h[i] + d[i];
+  }
+}
+
+// latitudinal diffusion (:585-590).  Tm/Tp, wm/wp: rows k-1 / k+1 (ignored where absent)
+__device__ __forceinline__ void dif_lat_strict(const f4& T0, const f4& Tm, const f4& Tp, const f4& wm,
+                                               const f4& wp, float ccy, int k, int ny, float d[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (k >= 1 && k <= ny - 2) d[i] = ccy * (wm.v[i] * (Tm.v[i] - T0.v[i]) + wp.v[i] * (Tp.v[i] - T0.v[i]));
+    else if (k == 0) d[i] = ccy * wp.v[i] * (-T0.v[i] + Tp.v[i]);
+    else d[i] = ccy * wm.v[i] * (Tm.v[i] - T0.v[i]);
+  }
+}
+
+// latitudinal advection (:756-795).  T/w at rows k-2,k-1,k+1,k+2
+__device__ __forceinline__ void adv_lat_strict(const f4& T0, const f4& Tm2, const f4& Tm1, const f4& Tp1,
+                                               const f4& Tp2, const f4& wm2, const f4& wm1, const f4& wp1,
+                                               const f4& wp2, const float v[4], float ccy, int k, int ny,
+                                               float d[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t0 = T0.v[i], vm = split_m(v[i]), vp = split_p(v[i]);
+    const float dm1 = wm1.v[i] * (t0 - Tm1.v[i]), dm2 = wm2.v[i] * (t0 - Tm2.v[i]);
+    const float dp1 = wp1.v[i] * (t0 - Tp1.v[i]), dp2 = wp2.v[i] * (t0 - Tp2.v[i]);
+    float r;
+    if (k == 0) r = ccy * (vp * (dp1 + dp2)) / 3.f;                              // :759-761
+    else if (k == 1) r = ccy * (-vm * (dm1) + vp * (dp1 + dp2) / 3.f);           // :766-769
+    else if (k <= ny - 3) r = ccy * (-vm * (dm1 + dm2) + vp * (dp1 + dp2)) / 3.f; // :774-778
+    else if (k == ny - 2) r = ccy * (-vm * (dm1 + dm2) / 3.f + vp * (dp1));      // :784-787
+    else r = ccy * (-vm * (dm1 + dm2)) / 3.f;                                    // :792-794
+    d[i] = r;
+  }
+}
+
+// ============================================================================================
+// FAST pieces (edge-flux form)
+// ============================================================================================
+struct Flux {
+  float Pp[10]; // Pp[m] = w[m+1]*(T[m+1]-T[m]), valid m = 4..9
+  float Pm[10]; // Pm[m] = w[m]  *(T[m+1]-T[m]), valid m = 1..6
+};
+
+__device__ __forceinline__ void make_flux(const float T[12], const float w[12], Flux& f) {
+#pragma unroll
+  for (int m = 1; m <= 9; ++m) {
+    const float e = T[m + 1] - T[m];
+    if (m >= 4) f.Pp[m] = w[m + 1] * e;
+    if (m <= 6) f.Pm[m] = w[m] * e;
+  }
+}
+
+// cs = cc/20
+__device__ __forceinline__ void dif_lon_fast(const Flux& f, float cs, float d[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 + i;
+    const float a = f.Pp[c] - f.Pm[c - 1], b = f.Pp[c + 1] - f.Pm[c - 2], g = f.Pp[c + 2] - f.Pm[c - 3];
+    d[i] = cs * (6.f * a + (3.f * b + g));
+  }
+}
+
+// cs = ccx/3
+__device__ __forceinline__ void adv_lon_full_fast(const Flux& f, const float T[12], const float w[12],
+                                                  const float u[4], float cs, float d[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 + i;
+    const float em2 = w[c - 2] * (T[c] - T[c - 2]), ep2 = w[c + 2] * (T[c] - T[c + 2]);
+    d[i] = cs * (split_p(u[i]) * (ep2 - f.Pp[c]) - split_m(u[i]) * (f.Pm[c - 1] + em2));
+  }
+}
+
+// cs = ccx2/20
+__device__ __forceinline__ void adv_lon_sub_fast(const Flux& f, const float T[12], const float w[12],
+                                                 const float u[4], float cs, bool last_quad, float d[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 + i;
+    const float am = 10.f * f.Pm[c - 1] + (4.f * f.Pm[c - 2] + f.Pm[c - 3]);
+    float ap = 10.f * f.Pp[c] + (4.f * f.Pp[c + 1] + f.Pp[c + 2]);
+    if (last_quad && i == 1) // :881 index bug: 4*w(jp1)*(T(jp1)-T(jp1)) + w(jp3)*(T(jp1)-T(jp3))
+      ap = 10.f * f.Pp[c] - w[c + 3] * (T[c + 1] - T[c + 3]);
+    d[i] = cs * (-split_p(u[i]) * ap - split_m(u[i]) * am);
+  }
+}
+
+__device__ __forceinline__ void clamp_add_fast(float T1h[4], float d[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d[i] = (d[i] <= -T1h[i]) ? -0.9f * T1h[i] : d[i];
+    T1h[i] = T1h[i] + d[i];
+  }
+}
+
+// Latitudinal part, both operators at once.  Missing rows are passed with w = 0.
+//   dif: ccy*(G-1 + G+1),  G(n) = w(k+n)*(T(k+n)-T0)
+//   adv: am*(-vm)*(D-1 + D-2) + ap*vp*(D+1 + D+2),  D(n) = w(k+n)*(T0-T(k+n)),
+//        am/ap = ccy/3 except am = ccy at k=1 and ap = ccy at k=ny-2 (:766-769,:784-787)
+__device__ __forceinline__ void lat_fast(const f4& T0, const f4& Tm2, const f4& Tm1, const f4& Tp1,
+                                         const f4& Tp2, const f4& wm2, const f4& wm1, const f4& wp1,
+                                         const f4& wp2, const float v[4], float ccy_dif, float am, float ap,
+                                         float ddif[4], float dadv[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t0 = T0.v[i];
+    const float gm1 = wm1.v[i] * (Tm1.v[i] - t0), gp1 = wp1.v[i] * (Tp1.v[i] - t0);
+    const float dm2 = wm2.v[i] * (t0 - Tm2.v[i]), dp2 = wp2.v[i] * (t0 - Tp2.v[i]);
+    ddif[i] = ccy_dif * (gm1 + gp1);
+    dadv[i] = ap * split_p(v[i]) * (dp2 - gp1) - am * split_m(v[i]) * (dm2 - gm1);
+  }
+}
+
+// ============================================================================================
+// Point physics (src/greb.f90:367-525).  One column of the model; everything fp32.
+// STRICT keeps the reference's operation order (x**4 = ((x*x)*x)*x as flang -O2 lowers it); the
+// only non-bit-exact parts are OCML expf/logf vs glibc (<= 1-2 ulp on fluxes).
+// ============================================================================================
+struct Phys { // namelist physics_par + derived capacities, broadcast to the kernel
+  float sig, ct_sens, da_ice, a_no_ice, a_cloud, Tl_ice1, Tl_ice2, To_ice1, To_ice2;
+  float co_turb, ce, cq_latent, cq_rain, z_air, r_qviwv, rho_air;
+  float p_emi[10];
+  float cap_ocean, cap_land, cap_air;
+  float dt; // float(dt)
+};
+
+__device__ __forceinline__ float pow4_ref(float x) {
+#pragma clang fp contract(off)
+  return x * x * x * x;
+}
+
+// a4 SWradiation :380-401 -> albedo, sw
+__device__ __forceinline__ void sw_radiation(const Phys& P, float Ts, float z_topo, float glacier, float cld,
+                                             float sw_solar, float& albedo, float& sw) {
+#pragma clang fp contract(off)
+  const float a_atmos = cld * P.a_cloud;
+  float a_surf = 0.f;
+  if (z_topo >= 0.f) {
+    if (Ts <= P.Tl_ice1) a_surf = P.a_no_ice + P.da_ice;
+    if (Ts >= P.Tl_ice2) a_surf = P.a_no_ice;
+    if (Ts > P.Tl_ice1 && Ts < P.Tl_ice2)
+      a_surf = P.a_no_ice + P.da_ice * (1.f - (Ts - P.Tl_ice1) / (P.Tl_ice2 - P.Tl_ice1));
+  } else {
+    if (Ts <= P.To_ice1) a_surf = P.a_no_ice + P.da_ice;
+    if (Ts >= P.To_ice2) a_surf = P.a_no_ice;
+    if (Ts > P.To_ice1 && Ts < P.To_ice2)
+      a_surf = P.a_no_ice + P.da_ice * (1.f - (Ts - P.To_ice1) / (P.To_ice2 - P.To_ice1));
+  }
+  if (glacier > 0.5f) a_surf = P.a_no_ice + P.da_ice;
+  albedo = a_surf + a_atmos - a_surf * a_atmos;
+  sw = sw_solar * (1.f - albedo);
+}
+
+// a5 LWradiation :420-432.  ez = exp(-z_topo/z_air) (== wz_air, :201), dTrad = -0.16*Tclim-5 (:176)
+__device__ __forceinline__ void lw_radiation(const Phys& P, float Ts, float Ta, float q, float co2, float ez,
+                                             float cld, float tclim, float& LWsurf, float& LWair_down,
+                                             float& em) {
+#pragma clang fp contract(off)
+  const float e_co2 = ez * co2;
+  const float e_vapor = ez * P.r_qviwv * q;
+  float e = P.p_emi[3] * logf(P.p_emi[0] * e_co2 + P.p_emi[1] * e_vapor + P.p_emi[2]) + P.p_emi[6]
+            + P.p_emi[4] * logf(P.p_emi[0] * e_co2 + P.p_emi[2])
+            + P.p_emi[5] * logf(P.p_emi[1] * e_vapor + P.p_emi[2]);
+  e = (P.p_emi[7] - cld) / P.p_emi[8] * (e - P.p_emi[9]) + P.p_emi[9];
+  em = e;
+  LWsurf = -P.sig * pow4_ref(Ts);
+  const float dTrad = -0.16f * tclim - 5.f;
+  LWair_down = -e * P.sig * pow4_ref(Ta + dTrad);
+}
+
+// a6 hydro :452-467
+__device__ __forceinline__ void hydro(const Phys& P, float Ts, float q, float u, float v, float z_topo,
+                                      float ez, float swet, float& Qlat, float& Qlat_air, float& dq_eva,
+                                      float& dq_rain) {
+#pragma clang fp contract(off)
+  float abswind = sqrtf(u * u + v * v);
+  if (z_topo > 0.f) abswind = sqrtf(abswind * abswind + 2.0f * 2.0f);
+  if (z_topo < 0.f) abswind = sqrtf(abswind * abswind + 3.0f * 3.0f);
+  float qs = 3.75e-3f * expf(17.08085f * (Ts - 273.15f) / (Ts - 273.15f + 234.175f));
+  qs = qs * ez;
+  Qlat = (q - qs) * abswind * P.cq_latent * P.rho_air * P.ce * swet;
+  dq_eva = -Qlat / P.cq_latent / P.r_qviwv;
+  dq_rain = P.cq_rain * q;
+  Qlat_air = -dq_rain * P.cq_latent * P.r_qviwv;
+}
+
+// a7 deep_ocean :505-523
+__device__ __forceinline__ void deep_ocean(const Phys& P, float Ts, float To, float z_topo, float mld,
+                                           float mld_prev, float z_ocean, float& dT_ocean, float& dTo) {
+#pragma clang fp contract(off)
+  float a = 0.f, b = 0.f;
+  const float dmld = mld - mld_prev;
+  if (z_topo < 0.f && Ts >= P.To_ice2 && dmld < 0.f) a = -dmld / (z_ocean - mld) * (Ts - To);
+  if (z_topo < 0.f && Ts >= P.To_ice2 && dmld > 0.f) b = dmld / mld * (To - Ts);
+  a = 0.5f * a; b = 0.5f * b;
+  const float Tx = P.To_ice2 > Ts ? P.To_ice2 : Ts;
+  a = a + P.dt * P.co_turb * (Tx - To) / (P.cap_ocean * (z_ocean - mld));
+  b = b + P.dt * P.co_turb * (To - Tx) / (P.cap_ocean * mld);
+  dTo = a; dT_ocean = b;
+}
+
+// a8 seaice :483-490 -> new cap_surf
+__device__ __forceinline__ float seaice(const Phys& P, float Ts, float z_topo, float glacier, float mld,
+                                        float cap_surf) {
+#pragma clang fp contract(off)
+  if (z_topo < 0.f) {
+    if (Ts <= P.To_ice1) cap_surf = P.cap_land;
+    if (Ts >= P.To_ice2) cap_surf = P.cap_ocean * mld;
+    if (Ts > P.To_ice1 && Ts < P.To_ice2)
+      cap_surf = P.cap_land + (P.cap_ocean * mld - P.cap_land) / (P.To_ice2 - P.To_ice1) * (Ts - P.To_ice1);
+  }
+  if (glacier > 0.5f) cap_surf = P.cap_land;
+  return cap_surf;
+}
+
+} // namespace greb

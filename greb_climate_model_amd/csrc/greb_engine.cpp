@@ -1,0 +1,536 @@
+// greb_engine.cpp -- the C ABI of include/greb_engine.h over the HIP kernels (greb_kernels.hip).
+//
+// Host-side responsibilities (everything the reference does once per run outside the time loops):
+//   * per-row grid tables, src/greb.f90:578-582, 652-654, 749-753, 838-840 (fp32, same expression
+//     order, glibc cosf like the flang-built reference)
+//   * derived fields of greb_model's preamble, src/greb.f90:176-216, and Toclim, :1088-1094
+//   * device residency: inputs are copied to HBM once in create; state, corrections and
+//     accumulators live in HBM between launches and in LDS/registers inside a launch
+//   * one launch of the fused member kernel per model year (730 steps) per phase
+// There is NO CPU fallback: without a HIP device create() fails with GREB_E_NOGPU.
+#include "../../include/greb_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "greb_kernels.h"
+
+using namespace greb;
+
+namespace {
+
+thread_local std::string g_last_error; // for failures before an engine exists
+
+int fail(greb_engine* e, int code, const std::string& msg);
+
+#define HIP_TRY(e, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t _err = (expr);                                                                 \
+    if (_err != hipSuccess)                                                                   \
+      return fail((e), (int)_err, std::string(#expr) + ": " + hipGetErrorString(_err));       \
+  } while (0)
+
+int nint_f(float x) { return (int)lroundf(x); }
+
+// src/greb.f90:578-582, 652-654 (diffusion), 749-753, 838-840 (advection)
+void compute_row_tables(const greb_params& p, float kappa, int nx, int ny, RowTables& g) {
+  std::memset(&g, 0, sizeof(g));
+  const float dlon = 360.f / (float)nx, dlat = 180.f / (float)ny; // :43-44
+  const float deg = 2.f * p.pi * 6.371e6f / 360.f;                // :578
+  const float dx = dlon, dy = dlat, dyy = dy * deg;               // :579
+  const float dtc = (float)p.dt_crcl;
+  g.dif_ccy = kappa * dtc / (dyy * dyy); // :581
+  g.adv_ccy = dtc / dyy / 2.f;           // :752
+  for (int k = 0; k < ny; ++k) {
+    const float lat = dlat * (float)(k + 1) - dlat / 2.f - 90.f;    // :580
+    const float dxlat = dx * deg * cosf(2.f * p.pi / 360.f * lat);  // :580
+    g.dif_ccx[k] = kappa * dtc / (dxlat * dxlat);                   // :582
+    g.adv_ccx[k] = dtc / dxlat / 2.f;                               // :753
+    g.subcycled[k] = !(dxlat > 2.5e5f);                             // :592, :799
+    {
+      float dd = (float)nint_f(dtc / (1.f * (dxlat * dxlat) / kappa)); // :652
+      if (dd < 1.f) dd = 1.f;
+      const int dtdff2 = (int)(dtc / dd);
+      // dtdff2 == 0 (384x192 polar rows) is undefined behaviour in the reference (NINT(Inf));
+      // the flang x86-64 build yields time2 = 1, ccx2 = 0 -- defined so here.
+      int t2 = dtdff2 == 0 ? 1 : nint_f(dtc / (float)dtdff2); // :653
+      g.dif_time2[k] = t2 < 1 ? 1 : t2;
+      g.dif_ccx2[k] = kappa * (float)dtdff2 / (dxlat * dxlat); // :654
+    }
+    {
+      float dd = (float)nint_f(dtc / (dxlat / 10.0f / 1.f)); // :838
+      if (dd < 1.f) dd = 1.f;
+      const int dtdff2 = (int)(dtc / dd);
+      int t2 = dtdff2 == 0 ? 1 : nint_f(dtc / (float)dtdff2); // :839
+      g.adv_time2[k] = t2 < 1 ? 1 : t2;
+      g.adv_ccx2[k] = (float)dtdff2 / dxlat / 2.f; // :840
+    }
+  }
+}
+
+Phys make_phys(const greb_params& p, const greb_member_overrides* o) {
+  Phys P;
+  auto pick = [](float base, float ov) { return std::isnan(ov) ? base : ov; };
+  P.sig = p.sig; P.ct_sens = p.ct_sens;
+  P.da_ice = o ? pick(p.da_ice, o->da_ice) : p.da_ice;
+  P.a_no_ice = o ? pick(p.a_no_ice, o->a_no_ice) : p.a_no_ice;
+  P.a_cloud = o ? pick(p.a_cloud, o->a_cloud) : p.a_cloud;
+  P.Tl_ice1 = p.Tl_ice1; P.Tl_ice2 = p.Tl_ice2; P.To_ice1 = p.To_ice1; P.To_ice2 = p.To_ice2;
+  P.co_turb = p.co_turb; P.ce = p.ce; P.cq_latent = p.cq_latent; P.cq_rain = p.cq_rain;
+  P.z_air = p.z_air; P.r_qviwv = p.r_qviwv; P.rho_air = p.rho_air;
+  for (int i = 0; i < 10; ++i) P.p_emi[i] = p.p_emi[i];
+  P.cap_ocean = p.cp_ocean * p.rho_ocean;          // :186
+  P.cap_land = p.cp_land * p.rho_land * p.d_land;  // :187
+  P.cap_air = p.cp_air * p.rho_air * p.d_air;      // :188
+  P.dt = (float)p.dt;
+  return P;
+}
+
+template <typename T>
+hipError_t dev_alloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)); }
+
+} // namespace
+
+struct greb_engine {
+  greb_params p{};
+  int nx = 0, ny = 0, np = 0, nm = 0, device = 0;
+  bool strict = false;
+  bool shared_corr = true; // all members share physics -> one flux-correction set
+  hipStream_t stream = nullptr;
+  // device
+  float *z_topo = nullptr, *glacier = nullptr, *sw_solar = nullptr;
+  float *tclim = nullptr, *qclim = nullptr, *uclim = nullptr, *vclim = nullptr, *mldclim = nullptr,
+        *cldclim = nullptr, *swetclim = nullptr;
+  float *toclim = nullptr, *z_ocean = nullptr, *wz_air = nullptr, *wz_vapor = nullptr;
+  float *state = nullptr, *acc = nullptr, *corr = nullptr;
+  int *corr_index = nullptr, *tab_index = nullptr;
+  RowTables* tabs = nullptr;
+  Phys* phys = nullptr;
+  float* co2_dev = nullptr; size_t co2_cap = 0;
+  float* monthly_dev = nullptr; size_t monthly_cap = 0;
+  float* yearly_dev = nullptr; size_t yearly_cap = 0;
+  // host copies needed later
+  std::vector<RowTables> h_tabs;
+  std::vector<Phys> h_phys;
+  // model clock
+  long long it_flux = 0; // steps done in the flux phase
+  long long it_scnr = 0; // steps done in the scenario
+  std::string last_error;
+};
+
+namespace {
+int fail(greb_engine* e, int code, const std::string& msg) {
+  if (e) e->last_error = msg;
+  g_last_error = msg;
+  return code;
+}
+
+int nsub_of(const greb_params& p) {
+  int t = nint_f((float)p.dt / (float)p.dt_crcl); // :543
+  return t < 1 ? 1 : t;
+}
+
+MemberArgs base_args(greb_engine* e) {
+  MemberArgs a{};
+  a.nx = e->nx; a.ny = e->ny; a.np = e->np;
+  a.z_topo = e->z_topo; a.glacier = e->glacier; a.sw_solar = e->sw_solar;
+  a.tclim = e->tclim; a.qclim = e->qclim; a.uclim = e->uclim; a.vclim = e->vclim;
+  a.mldclim = e->mldclim; a.cldclim = e->cldclim; a.swetclim = e->swetclim;
+  a.toclim = e->toclim; a.z_ocean = e->z_ocean; a.wz_air = e->wz_air; a.wz_vapor = e->wz_vapor;
+  a.state = e->state; a.acc = e->acc; a.corr = e->corr; a.corr_index = e->corr_index;
+  a.tabs = e->tabs; a.tab_index = e->tab_index; a.phys = e->phys;
+  a.nsub = nsub_of(e->p);
+  a.co2_flux = e->p.co2_flux;
+  a.ipx = e->p.ipx; a.ipy = e->p.ipy;
+  return a;
+}
+
+int ensure(greb_engine* e, float** buf, size_t* cap, size_t n) {
+  if (*cap >= n) return 0;
+  if (*buf) HIP_TRY(e, hipFree(*buf));
+  *buf = nullptr; *cap = 0;
+  HIP_TRY(e, dev_alloc(buf, n));
+  *cap = n;
+  return 0;
+}
+} // namespace
+
+extern "C" {
+
+void greb_params_default(greb_params* p) {
+  // src/greb.f90:49-53, 68-104; constant expressions folded in fp32 like the compiler does
+  std::memset(p, 0, sizeof(*p));
+  p->pi = 3.1416f; p->sig = 5.6704e-8f; p->rho_ocean = 999.1f; p->rho_land = 2600.f; p->rho_air = 1.2f;
+  p->cp_ocean = 4186.f; p->cp_land = 926.222f; p->cp_air = 1005.f; p->eps = 1.f;
+  p->d_ocean = 50.f; p->d_land = 2.f; p->d_air = 5000.f; p->ct_sens = 22.5f; p->da_ice = 0.25f;
+  p->a_no_ice = 0.1f; p->a_cloud = 0.35f;
+  p->Tl_ice1 = 273.15f - 10.f; p->Tl_ice2 = 273.15f; p->To_ice1 = 273.15f - 7.f; p->To_ice2 = 273.15f - 1.7f;
+  p->co_turb = 5.0f; p->kappa = 8e5f; p->ce = 2e-3f; p->cq_latent = 2.257e6f;
+  p->cq_rain = -0.1f / 24.f / 3600.f; p->z_air = 8400.f; p->z_vapor = 5000.f; p->r_qviwv = 2.6736e3f;
+  const float pe[10] = {9.0721f, 106.7252f, 61.5562f, 0.0179f, 0.0028f, 0.0570f, 0.3462f, 2.3406f, 0.7032f, 1.0662f};
+  std::memcpy(p->p_emi, pe, sizeof(pe));
+  p->co2_flux = 298.f;
+  p->ipx = 1; p->ipy = 1; p->year0 = 1940; p->dt = 12 * 3600; p->dt_crcl = 1800;
+}
+
+const char* greb_engine_last_error(const greb_engine* e) {
+  return e ? e->last_error.c_str() : g_last_error.c_str();
+}
+
+const char* greb_device_info(int device) {
+  static thread_local std::string s;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= device || device < 0) {
+    s = "{\"error\": \"no HIP device\"}";
+    return s.c_str();
+  }
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, device) != hipSuccess) { s = "{\"error\": \"hipGetDeviceProperties\"}"; return s.c_str(); }
+  char buf[512];
+  std::snprintf(buf, sizeof(buf),
+                "{\"name\": \"%s\", \"arch\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"mem_clock_mhz\": %d, "
+                "\"hbm_gb\": %.1f, \"lds_per_block\": %zu, \"l2_mb\": %.1f, \"wave\": %d}",
+                pr.name, pr.gcnArchName, pr.multiProcessorCount, pr.clockRate / 1000, pr.memoryClockRate / 1000,
+                pr.totalGlobalMem / 1073741824.0, pr.sharedMemPerBlock, pr.l2CacheSize / 1048576.0, pr.warpSize);
+  s = buf;
+  return s.c_str();
+}
+
+int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* f, int n_members,
+                       const greb_member_overrides* overrides, int device, unsigned flags, greb_engine** out) {
+  if (!p || !f || !out || n_members < 1 || nx < 12 || (nx & 3) || ny < 5 || ny > kMaxNy)
+    return fail(nullptr, GREB_E_INVALID, "greb_engine_create: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
+    return fail(nullptr, GREB_E_NOGPU, "greb_engine_create: no HIP device (the engine has no CPU path)");
+  if (!(nx == 96 && ny == 48))
+    return fail(nullptr, GREB_E_UNSUPPORTED,
+                "greb_engine_create: the fused member engine supports the 96x48 grid only in this build "
+                "(the batched diffusion/advection/circulation entry points take any grid)");
+  if (p->ipx < 1 || p->ipx > nx || p->ipy < 1 || p->ipy > ny)
+    return fail(nullptr, GREB_E_INVALID, "greb_engine_create: ipx/ipy outside the grid");
+  greb_engine* e = new (std::nothrow) greb_engine();
+  if (!e) return fail(nullptr, GREB_E_INVALID, "out of host memory");
+  *out = e; // returned even on failure so last_error can be read; caller destroys
+  e->p = *p; e->nx = nx; e->ny = ny; e->np = nx * ny; e->nm = n_members; e->device = device;
+  e->strict = (flags & GREB_F_STRICT) != 0;
+  const size_t np = (size_t)e->np, n3 = np * kNT, nm = (size_t)n_members;
+  HIP_TRY(e, hipSetDevice(device));
+  HIP_TRY(e, hipStreamCreate(&e->stream));
+
+  auto up = [&](float** d, const float* h, size_t n) -> hipError_t {
+    hipError_t err = dev_alloc(d, n);
+    if (err != hipSuccess) return err;
+    return hipMemcpy(*d, h, n * sizeof(float), hipMemcpyHostToDevice);
+  };
+  HIP_TRY(e, up(&e->z_topo, f->z_topo, np));
+  HIP_TRY(e, up(&e->glacier, f->glacier, np));
+  HIP_TRY(e, up(&e->sw_solar, f->sw_solar, (size_t)kNT * ny));
+  HIP_TRY(e, up(&e->tclim, f->tclim, n3));
+  HIP_TRY(e, up(&e->qclim, f->qclim, n3));
+  HIP_TRY(e, up(&e->uclim, f->uclim, n3));
+  HIP_TRY(e, up(&e->vclim, f->vclim, n3));
+  HIP_TRY(e, up(&e->mldclim, f->mldclim, n3));
+  HIP_TRY(e, up(&e->cldclim, f->cldclim, n3));
+  HIP_TRY(e, up(&e->swetclim, f->swetclim, n3));
+
+  // derived fields (host, once): Toclim :1088-1094, z_ocean :179-183, wz_* :201-202
+  std::vector<float> toclim(np), z_ocean(np), wz_air(np), wz_vapor(np);
+  for (size_t i = 0; i < np; ++i) {
+    float mn = f->tclim[i], mx = 0.f;
+    for (int t = 0; t < kNT; ++t) {
+      const float v = f->tclim[(size_t)t * np + i]; if (v < mn) mn = v;
+      const float d = f->mldclim[(size_t)t * np + i]; if (d > mx) mx = d;
+    }
+    if (mn - 273.15f < -1.7f) mn = -1.7f + 273.15f;
+    toclim[i] = mn;
+    z_ocean[i] = 3.0f * mx;
+    wz_air[i] = expf(-f->z_topo[i] / p->z_air);
+    wz_vapor[i] = expf(-f->z_topo[i] / p->z_vapor);
+  }
+  HIP_TRY(e, up(&e->toclim, toclim.data(), np));
+  HIP_TRY(e, up(&e->z_ocean, z_ocean.data(), np));
+  HIP_TRY(e, up(&e->wz_air, wz_air.data(), np));
+  HIP_TRY(e, up(&e->wz_vapor, wz_vapor.data(), np));
+
+  // per-member physics, grid tables (deduplicated by kappa), correction-set mapping
+  e->h_phys.resize(nm);
+  std::vector<int> tab_index(nm), corr_index(nm);
+  std::vector<float> kappas;
+  e->shared_corr = true;
+  for (size_t m = 0; m < nm; ++m) {
+    const greb_member_overrides* o = overrides ? overrides + m : nullptr;
+    e->h_phys[m] = make_phys(*p, o);
+    const float kap = (o && !std::isnan(o->kappa)) ? o->kappa : p->kappa;
+    size_t ti = 0;
+    for (; ti < kappas.size(); ++ti) if (kappas[ti] == kap) break;
+    if (ti == kappas.size()) {
+      kappas.push_back(kap);
+      RowTables t; compute_row_tables(*p, kap, nx, ny, t);
+      e->h_tabs.push_back(t);
+    }
+    tab_index[m] = (int)ti;
+    if (o && !(std::isnan(o->da_ice) && std::isnan(o->a_no_ice) && std::isnan(o->a_cloud) && std::isnan(o->kappa)))
+      e->shared_corr = false;
+  }
+  for (size_t m = 0; m < nm; ++m) corr_index[m] = e->shared_corr ? 0 : (int)m;
+  HIP_TRY(e, dev_alloc(&e->phys, nm));
+  HIP_TRY(e, hipMemcpy(e->phys, e->h_phys.data(), nm * sizeof(Phys), hipMemcpyHostToDevice));
+  HIP_TRY(e, dev_alloc(&e->tabs, e->h_tabs.size()));
+  HIP_TRY(e, hipMemcpy(e->tabs, e->h_tabs.data(), e->h_tabs.size() * sizeof(RowTables), hipMemcpyHostToDevice));
+  HIP_TRY(e, dev_alloc(&e->tab_index, nm));
+  HIP_TRY(e, hipMemcpy(e->tab_index, tab_index.data(), nm * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(e, dev_alloc(&e->corr_index, nm));
+  HIP_TRY(e, hipMemcpy(e->corr_index, corr_index.data(), nm * sizeof(int), hipMemcpyHostToDevice));
+
+  const size_t ncorr = e->shared_corr ? 1 : nm;
+  HIP_TRY(e, dev_alloc(&e->corr, ncorr * 3 * n3));
+  HIP_TRY(e, hipMemset(e->corr, 0, ncorr * 3 * n3 * sizeof(float))); // time_flux = 0 => zero corrections (A.9-10)
+  HIP_TRY(e, dev_alloc(&e->acc, nm * 6 * np));
+  HIP_TRY(e, hipMemset(e->acc, 0, nm * 6 * np * sizeof(float)));
+
+  // initial state :194-197 and initial cap_surf :190-191
+  std::vector<float> st(5 * np);
+  const size_t last = (size_t)(kNT - 1) * np;
+  HIP_TRY(e, dev_alloc(&e->state, nm * 5 * np));
+  for (size_t m = 0; m < nm; ++m) {
+    const Phys& P = e->h_phys[m];
+    for (size_t i = 0; i < np; ++i) {
+      st[i] = f->tclim[last + i]; st[np + i] = st[i]; st[2 * np + i] = toclim[i]; st[3 * np + i] = f->qclim[last + i];
+      float c = 0.f;
+      if (f->z_topo[i] > 0.f) c = P.cap_land;
+      if (f->z_topo[i] <= 0.f) c = P.cap_ocean * f->mldclim[i];
+      st[4 * np + i] = c;
+    }
+    HIP_TRY(e, hipMemcpy(e->state + m * 5 * np, st.data(), 5 * np * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+int greb_engine_destroy(greb_engine* e) {
+  if (!e) return 0;
+  hipSetDevice(e->device);
+  void* ptrs[] = {e->z_topo, e->glacier, e->sw_solar, e->tclim, e->qclim, e->uclim, e->vclim, e->mldclim,
+                  e->cldclim, e->swetclim, e->toclim, e->z_ocean, e->wz_air, e->wz_vapor, e->state, e->acc,
+                  e->corr, e->corr_index, e->tab_index, e->tabs, e->phys, e->co2_dev, e->monthly_dev, e->yearly_dev};
+  for (void* q : ptrs) if (q) hipFree(q);
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return 0;
+}
+
+int greb_engine_flux_correction(greb_engine* e, int years, float* yearly) {
+  if (!e || years < 0) return fail(e, GREB_E_INVALID, "flux_correction: bad argument");
+  if (years == 0) return 0;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t np = (size_t)e->np;
+  const int nrun = e->shared_corr ? 1 : e->nm; // identical members: integrate one, broadcast
+  if (int rc = ensure(e, &e->yearly_dev, &e->yearly_cap, (size_t)e->nm * years * 2)) return rc;
+  HIP_TRY(e, hipMemsetAsync(e->yearly_dev, 0, (size_t)e->nm * years * 2 * sizeof(float), e->stream));
+  for (int y = 0; y < years; ++y) {
+    MemberArgs a = base_args(e);
+    a.flux_phase = 1;
+    a.it0 = e->it_flux + 1 + (long long)y * kNT; a.nsteps = kNT;
+    a.monthly = nullptr; a.monthly_years = years; a.year_out0 = y;
+    a.yearly = e->yearly_dev; a.yearly_years = years; a.yearly_year0 = y;
+    HIP_TRY(e, launch_member_kernel(a, nrun, e->strict, e->stream));
+  }
+  if (e->shared_corr && e->nm > 1) { // the spun-up state (incl. cap_surf) is every member's start (A.8)
+    for (int m = 1; m < e->nm; ++m)
+      HIP_TRY(e, hipMemcpyAsync(e->state + (size_t)m * 5 * np, e->state, 5 * np * sizeof(float),
+                                hipMemcpyDeviceToDevice, e->stream));
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->it_flux += (long long)years * kNT;
+  if (yearly) {
+    HIP_TRY(e, hipMemcpy(yearly, e->yearly_dev, (size_t)e->nm * years * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (e->shared_corr)
+      for (int m = 1; m < e->nm; ++m) std::memcpy(yearly + (size_t)m * years * 2, yearly, (size_t)years * 2 * sizeof(float));
+  }
+  return 0;
+}
+
+int greb_engine_run(greb_engine* e, int years, const float* co2_ppm, float* monthly, float* yearly,
+                    unsigned run_flags) {
+  if (!e || years < 1 || !co2_ppm || !monthly) return fail(e, GREB_E_INVALID, "run: bad argument");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t np = (size_t)e->np, nm = (size_t)e->nm;
+  const size_t rec_year = 12 * 5 * np; // floats per member-year
+  const bool dev_out = (run_flags & GREB_RUN_DEVICE_OUT) != 0;
+  if (int rc = ensure(e, &e->co2_dev, &e->co2_cap, nm * years)) return rc;
+  HIP_TRY(e, hipMemcpyAsync(e->co2_dev, co2_ppm, nm * years * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  if (int rc = ensure(e, &e->yearly_dev, &e->yearly_cap, nm * years * 2)) return rc;
+  HIP_TRY(e, hipMemsetAsync(e->yearly_dev, 0, nm * years * 2 * sizeof(float), e->stream));
+  int chunk = years;
+  if (!dev_out) {
+    const size_t budget = (size_t)1 << 30; // floats (4 GiB) of staging per chunk
+    chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)years, budget / (nm * rec_year)));
+    if (int rc = ensure(e, &e->monthly_dev, &e->monthly_cap, nm * chunk * rec_year)) return rc;
+  }
+  for (int y0 = 0; y0 < years; y0 += chunk) {
+    const int cy = std::min(chunk, years - y0);
+    for (int y = 0; y < cy; ++y) {
+      MemberArgs a = base_args(e);
+      a.flux_phase = 0;
+      a.it0 = e->it_scnr + 1 + (long long)(y0 + y) * kNT; a.nsteps = kNT;
+      a.co2 = e->co2_dev; a.co2_stride = years; a.co2_year0 = y0 + y;
+      if (dev_out) { a.monthly = monthly; a.monthly_years = years; a.year_out0 = y0 + y; }
+      else { a.monthly = e->monthly_dev; a.monthly_years = chunk; a.year_out0 = y; }
+      a.yearly = e->yearly_dev; a.yearly_years = years; a.yearly_year0 = y0 + y;
+      HIP_TRY(e, launch_member_kernel(a, e->nm, e->strict, e->stream));
+    }
+    if (!dev_out) {
+      HIP_TRY(e, hipMemcpy2DAsync(monthly + (size_t)y0 * rec_year, (size_t)years * rec_year * sizeof(float),
+                                  e->monthly_dev, (size_t)chunk * rec_year * sizeof(float),
+                                  (size_t)cy * rec_year * sizeof(float), nm, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->it_scnr += (long long)years * kNT;
+  if (yearly) HIP_TRY(e, hipMemcpy(yearly, e->yearly_dev, nm * years * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int greb_engine_get_state(greb_engine* e, int member, float* state5) {
+  if (!e || member < 0 || member >= e->nm || !state5) return fail(e, GREB_E_INVALID, "get_state: bad argument");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemcpy(state5, e->state + (size_t)member * 5 * e->np, (size_t)5 * e->np * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int greb_engine_get_corrections(greb_engine* e, int member, float* corr, float* state5) {
+  if (!e || member < 0 || member >= e->nm) return fail(e, GREB_E_INVALID, "get_corrections: bad argument");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t n = (size_t)3 * kNT * e->np, ci = e->shared_corr ? 0 : (size_t)member;
+  if (corr) HIP_TRY(e, hipMemcpy(corr, e->corr + ci * n, n * sizeof(float), hipMemcpyDeviceToHost));
+  if (state5) return greb_engine_get_state(e, member, state5);
+  return 0;
+}
+
+int greb_engine_set_corrections(greb_engine* e, int member, const float* corr, const float* state5) {
+  if (!e || member < -1 || member >= e->nm) return fail(e, GREB_E_INVALID, "set_corrections: bad argument");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t n = (size_t)3 * kNT * e->np, s5 = (size_t)5 * e->np;
+  const int m0 = member < 0 ? 0 : member, m1 = member < 0 ? e->nm : member + 1; // -1 = every member
+  for (int m = m0; m < m1; ++m) {
+    const size_t ci = e->shared_corr ? 0 : (size_t)m;
+    if (corr && (ci == (size_t)m || m == m0)) HIP_TRY(e, hipMemcpy(e->corr + ci * n, corr, n * sizeof(float), hipMemcpyHostToDevice));
+    if (state5) HIP_TRY(e, hipMemcpy(e->state + (size_t)m * s5, state5, s5 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- batched single routines
+namespace {
+struct DevBuf {
+  float* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+};
+int batched_common(const greb_params* p, int nx, int ny, int batch, int device) {
+  if (!p || nx < 12 || (nx & 3) || ny < 5 || ny > kMaxNy || batch < 1) return fail(nullptr, GREB_E_INVALID, "batched: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
+    return fail(nullptr, GREB_E_NOGPU, "batched: no HIP device (no CPU path)");
+  hipError_t err = hipSetDevice(device);
+  if (err != hipSuccess) return fail(nullptr, (int)err, "hipSetDevice");
+  return 0;
+}
+} // namespace
+
+#define HIP_TRY0(expr) HIP_TRY(nullptr, expr)
+
+int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, const float* T1_dev,
+                               const float* wz_dev, float* dX_dev, int strict, int sweeps, void* stream) {
+  if (!p || nx < 12 || (nx & 3) || ny < 5 || ny > kMaxNy || batch < 1 || sweeps < 1)
+    return fail(nullptr, GREB_E_INVALID, "diffusion_batched_dev: bad argument");
+  // table lives in a small cached device buffer keyed by (params, grid)
+  static thread_local RowTables* tab_dev = nullptr;
+  static thread_local RowTables tab_host;
+  RowTables t; compute_row_tables(*p, p->kappa, nx, ny, t);
+  if (!tab_dev) { HIP_TRY0(dev_alloc(&tab_dev, 1)); std::memset(&tab_host, 0xff, sizeof(tab_host)); }
+  if (std::memcmp(&t, &tab_host, sizeof(t)) != 0) {
+    HIP_TRY0(hipMemcpy(tab_dev, &t, sizeof(t), hipMemcpyHostToDevice));
+    tab_host = t;
+  }
+  for (int i = 0; i < sweeps; ++i)
+    HIP_TRY0(launch_diffusion(T1_dev, wz_dev, dX_dev, tab_dev, nx, ny, batch, strict != 0, (hipStream_t)stream));
+  return 0;
+}
+
+int greb_diffusion_batched(const greb_params* p, int nx, int ny, int batch, const float* T1, const float* wz,
+                           float* dX, int strict, int device) {
+  if (int rc = batched_common(p, nx, ny, batch, device)) return rc;
+  const size_t n = (size_t)batch * nx * ny;
+  DevBuf a, b, c;
+  HIP_TRY0(dev_alloc(&a.p, n)); HIP_TRY0(dev_alloc(&b.p, n)); HIP_TRY0(dev_alloc(&c.p, n));
+  HIP_TRY0(hipMemcpy(a.p, T1, n * 4, hipMemcpyHostToDevice));
+  HIP_TRY0(hipMemcpy(b.p, wz, n * 4, hipMemcpyHostToDevice));
+  if (int rc = greb_diffusion_batched_dev(p, nx, ny, batch, a.p, b.p, c.p, strict, 1, nullptr)) return rc;
+  HIP_TRY0(hipDeviceSynchronize());
+  HIP_TRY0(hipMemcpy(dX, c.p, n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static int adv_or_circ(bool circ, const greb_params* p, int nx, int ny, int batch, const float* X, const float* wz,
+                       const float* u, const float* v, float* dX, int strict, int device) {
+  if (int rc = batched_common(p, nx, ny, batch, device)) return rc;
+  const size_t n = (size_t)batch * nx * ny;
+  DevBuf a, b, c, d, o, scr;
+  RowTables t; compute_row_tables(*p, p->kappa, nx, ny, t);
+  RowTables* tab_dev = nullptr;
+  HIP_TRY0(dev_alloc(&tab_dev, 1));
+  DevBuf tabhold; tabhold.p = reinterpret_cast<float*>(tab_dev);
+  HIP_TRY0(hipMemcpy(tab_dev, &t, sizeof(t), hipMemcpyHostToDevice));
+  HIP_TRY0(dev_alloc(&a.p, n)); HIP_TRY0(dev_alloc(&b.p, n)); HIP_TRY0(dev_alloc(&c.p, n));
+  HIP_TRY0(dev_alloc(&d.p, n)); HIP_TRY0(dev_alloc(&o.p, n));
+  HIP_TRY0(hipMemcpy(a.p, X, n * 4, hipMemcpyHostToDevice));
+  HIP_TRY0(hipMemcpy(b.p, wz, n * 4, hipMemcpyHostToDevice));
+  HIP_TRY0(hipMemcpy(c.p, u, n * 4, hipMemcpyHostToDevice));
+  HIP_TRY0(hipMemcpy(d.p, v, n * 4, hipMemcpyHostToDevice));
+  if (circ) {
+    HIP_TRY0(dev_alloc(&scr.p, 3 * n));
+    HIP_TRY0(launch_circulation(a.p, b.p, c.p, d.p, o.p, scr.p, tab_dev, nx, ny, batch, nsub_of(*p), strict != 0, nullptr));
+  } else {
+    HIP_TRY0(launch_advection(a.p, b.p, c.p, d.p, o.p, tab_dev, nx, ny, batch, strict != 0, nullptr));
+  }
+  HIP_TRY0(hipDeviceSynchronize());
+  HIP_TRY0(hipMemcpy(dX, o.p, n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int greb_advection_batched(const greb_params* p, int nx, int ny, int batch, const float* T1, const float* wz,
+                           const float* u, const float* v, float* dX, int strict, int device) {
+  return adv_or_circ(false, p, nx, ny, batch, T1, wz, u, v, dX, strict, device);
+}
+
+int greb_circulation_batched(const greb_params* p, int nx, int ny, int batch, const float* X, const float* wz,
+                             const float* u, const float* v, float* dX, int strict, int device) {
+  return adv_or_circ(true, p, nx, ny, batch, X, wz, u, v, dX, strict, device);
+}
+
+int greb_engine_point_physics(greb_engine* e, int ityr, float co2, const float* in5, float* out15) {
+  if (!e || ityr < 1 || ityr > kNT || !in5 || !out15) return fail(e, GREB_E_INVALID, "point_physics: bad argument");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t np = (size_t)e->np;
+  DevBuf in, out;
+  HIP_TRY(e, dev_alloc(&in.p, 5 * np)); HIP_TRY(e, dev_alloc(&out.p, 15 * np));
+  HIP_TRY(e, hipMemcpy(in.p, in5, 5 * np * 4, hipMemcpyHostToDevice));
+  PointArgs a{};
+  a.nx = e->nx; a.ny = e->ny; a.np = e->np; a.ityr = ityr; a.co2 = co2;
+  a.z_topo = e->z_topo; a.glacier = e->glacier; a.sw_solar = e->sw_solar; a.tclim = e->tclim;
+  a.uclim = e->uclim; a.vclim = e->vclim; a.mldclim = e->mldclim; a.cldclim = e->cldclim; a.swetclim = e->swetclim;
+  a.z_ocean = e->z_ocean; a.wz_air = e->wz_air; a.phys = e->h_phys[0]; a.in5 = in.p; a.out15 = out.p;
+  HIP_TRY(e, launch_point_physics(a, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  HIP_TRY(e, hipMemcpy(out15, out.p, 15 * np * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,68 @@
+// greb_kernels.h -- launch interface between the C-ABI host code (greb_engine.cpp) and the HIP
+// kernels (greb_kernels.hip).  Internal; the public surface is include/greb_engine.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "greb_device.h"
+
+namespace greb {
+
+constexpr int kNT = 730;
+
+// Everything the fused member kernel needs (passed by value as a kernel argument).
+struct MemberArgs {
+  int nx, ny, np;
+  // shared static fields (HBM, read-only)
+  const float *z_topo, *glacier, *sw_solar;
+  const float *tclim, *qclim, *uclim, *vclim, *mldclim, *cldclim, *swetclim;
+  const float *toclim, *z_ocean, *wz_air, *wz_vapor;
+  // per member
+  float* state;          // [nm][5][np]   Ts, Ta, To, q, cap_surf
+  float* acc;            // [nm][6][np]   Tmm, Tamm, Tomm, qmm, apmm (src/greb.f90:149), tsmn (:145)
+  float* corr;           // [ncorr][3][730][np]  TF_correct, qF_correct, ToF_correct (:110)
+  const int* corr_index; // [nm] -> which correction set a member reads/writes
+  const RowTables* tabs; // [ntab]
+  const int* tab_index;  // [nm]
+  const Phys* phys;      // [nm]
+  // run control
+  int flux_phase;        // 1: qflux_correction (:311-364), 0: scenario (:228-234 + time_loop)
+  long long it0;         // `it` of the first step of this launch (1-based)
+  int nsteps;
+  int nsub;              // max(1,nint(dt/dt_crcl)) = 24 (:543)
+  const float* co2;      // scenario: [nm][co2_stride] annual series; flux: unused
+  int co2_stride;
+  int co2_year0;         // index into the series of the year containing it0
+  float co2_flux;
+  float* monthly;        // [nm][rec_stride_years][12][5][np]; record for (year_out, month)
+  int monthly_years;     // years per member in `monthly`
+  int year_out0;         // output-year index of the year containing it0
+  float* yearly;         // [nm][yearly_years][2] or nullptr
+  int yearly_years, yearly_year0;
+  int ipx, ipy;          // 1-based
+};
+
+// fused engine, 96x48 only (whole member state resident in one CU's LDS)
+hipError_t launch_member_kernel(const MemberArgs& a, int n_members, bool strict, hipStream_t s);
+
+// batched single-routine kernels, any grid with nx % 4 == 0, ny <= kMaxNy
+hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const RowTables* tab_dev, int nx,
+                            int ny, int batch, bool strict, hipStream_t s);
+hipError_t launch_advection(const float* T1, const float* wz, const float* u, const float* v, float* dX,
+                            const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s);
+// 24 sub-steps; 96x48 uses the fused LDS loop of the engine, other grids launch per sub-step
+hipError_t launch_circulation(const float* X, const float* wz, const float* u, const float* v, float* dX,
+                              float* scratch /* 3*batch*np */, const RowTables* tab_dev, int nx, int ny,
+                              int batch, int nsub, bool strict, hipStream_t s);
+
+struct PointArgs {
+  int nx, ny, np, ityr;
+  float co2;
+  const float *z_topo, *glacier, *sw_solar, *tclim, *uclim, *vclim, *mldclim, *cldclim, *swetclim;
+  const float *z_ocean, *wz_air;
+  Phys phys;
+  const float* in5; // Ts, Ta, To, q, cap_surf
+  float* out15;
+};
+hipError_t launch_point_physics(const PointArgs& a, hipStream_t s);
+
+} // namespace greb

@@ -165,6 +165,9 @@ def main():
                         december=np.stack(dec), yearly=np.stack(yrs))
     manifest["items"]["ensemble_g96"] = {"time_flux": 1, "time_scnr": 3, "levels": levels}
 
+    manifest["input_sha256"] = {k: hashlib.sha256(np.ascontiguousarray(getattr(inp, k)).tobytes()).hexdigest()
+                                for k in ("tclim", "qclim", "uclim", "vclim", "mldclim", "cldclim", "swetclim",
+                                          "z_topo", "glacier", "sw_solar")}
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print("wrote MANIFEST.json")

@@ -1,0 +1,219 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden vectors
+minted from the compiled reference.
+
+Bars:
+  * STRICT stencils (diffusion / advection / circulation): BIT-EXACT -- they contain only
+    + - * / in the reference's order, IEEE division, no FMA.
+  * FAST stencils: increments differ by re-association only; tolerance 2e-6 relative to the
+    largest increment of the field (fp32 eps = 6e-8, ~40 operations).
+  * point physics: OCML expf/logf vs glibc -> <= 4 ulp on the affected fluxes, exact elsewhere.
+  * whole runs, monthly means vs the reference Fortran: north-star tolerance < 1e-4 K RMS for
+    Tsurf/Tair/Tocean; companions q < 2e-8, albedo < 1e-6 (the reference's own
+    compiler-flag noise floor is 1.7e-5 K).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from greb_climate_model_amd import engine
+    engine.lib()  # fails loudly if libgreb_hip.so is missing
+    return engine
+
+
+def _fields(inputs, oracle_lib, params, ityr, seed=3):
+    o = oracle_lib.Oracle(inputs, params)
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    Ta = (inputs.tclim[ityr - 1] + (1.5 * rng.standard_normal((48, 96))).astype(f)).astype(f)
+    q = (inputs.qclim[ityr - 1] * (f(0.9) + f(0.2) * rng.random((48, 96)).astype(f))).astype(f)
+    return o, Ta, q, o.field(5).copy(), o.field(6).copy(), inputs.uclim[ityr - 1], inputs.vclim[ityr - 1]
+
+
+# ------------------------------------------------------------------------------------ stencils
+@pytest.mark.parametrize("ityr", [1, 365, 730])
+def test_strict_stencils_bit_exact_vs_golden(eng_mod, params, routine_golden, inputs, ityr):
+    g = routine_golden
+    Ta, q = g[f"t{ityr}_in_Ta"], g[f"t{ityr}_in_q"]
+    wa, wv = g["wz_air"], g["wz_vapor"]
+    u, v = inputs.uclim[ityr - 1], inputs.vclim[ityr - 1]
+    X = np.stack([Ta, q]); W = np.stack([wa, wv]); U = np.stack([u, u]); V = np.stack([v, v])
+    d = eng_mod.diffusion(X, W, params, strict=True)
+    assert np.array_equal(d[0], g[f"t{ityr}_out_dif_Ta"]) and np.array_equal(d[1], g[f"t{ityr}_out_dif_q"])
+    a = eng_mod.advection(X, W, U, V, params, strict=True)
+    assert np.array_equal(a[0], g[f"t{ityr}_out_adv_Ta"]) and np.array_equal(a[1], g[f"t{ityr}_out_adv_q"])
+    c = eng_mod.circulation(X, W, U, V, params, strict=True)
+    assert np.array_equal(c[0], g[f"t{ityr}_out_crc_Ta"]) and np.array_equal(c[1], g[f"t{ityr}_out_crc_q"])
+
+
+@pytest.mark.parametrize("ityr", [1, 365, 730])
+def test_fast_stencils_within_reassociation_tolerance(eng_mod, params, routine_golden, inputs, ityr):
+    g = routine_golden
+    Ta, q = g[f"t{ityr}_in_Ta"], g[f"t{ityr}_in_q"]
+    X = np.stack([Ta, q]); W = np.stack([g["wz_air"], g["wz_vapor"]])
+    u, v = inputs.uclim[ityr - 1], inputs.vclim[ityr - 1]
+    U = np.stack([u, u]); V = np.stack([v, v])
+    for name, got in (("dif", eng_mod.diffusion(X, W, params)), ("adv", eng_mod.advection(X, W, U, V, params)),
+                      ("crc", eng_mod.circulation(X, W, U, V, params))):
+        for i, tr in enumerate(("Ta", "q")):
+            ref = g[f"t{ityr}_out_{name}_{tr}"]
+            # rows 1-10/39-48 return fl(fl(T+d)-T): quantised to ulp(T); allow one ulp of the state there
+            tol = 2e-6 * np.abs(ref).max() + (np.spacing(np.abs(X[i]).max()) if name != "crc" else 24 * np.spacing(np.abs(X[i]).max()))
+            assert np.abs(got[i].astype(np.float64) - ref).max() <= tol, (name, tr)
+
+
+def test_stencil_edge_cases_strict(eng_mod, params, inputs, oracle_lib):
+    """Cases the smooth fixtures never reach: the clamp (src/greb.f90:715,907) on a tracer with
+    zeros and spikes, u<0 in sub-cycled rows (the :881 index bug), rough weights, a constant field."""
+    o, Ta, q, wa, wv, u, v = _fields(inputs, oracle_lib, params, 100)
+    rng = np.random.default_rng(11)
+    f = np.float32
+    spiky = (q * (rng.random((48, 96)) < 0.7)).astype(f)            # 30 % exact zeros
+    spiky[0, ::7] = f(0.05); spiky[47, 3::5] = f(0.08); spiky[5, 90:] = f(0.03)   # polar spikes -> clamp
+    rough_w = (f(0.05) + rng.random((48, 96)).astype(f) * f(0.95)).astype(f)
+    west = (-np.abs(u) - f(3)).astype(f)                             # u < 0 everywhere
+    const = np.full((48, 96), f(281.5))
+    cases = [(spiky, wv, u, v), (spiky, rough_w, west, v), (Ta, rough_w, west, (-v).astype(f)), (const, wa, u, v),
+             (Ta, wa, np.zeros_like(u), np.zeros_like(v))]
+    for X, W, U, V in cases:
+        assert np.array_equal(eng_mod.diffusion(X, W, params, strict=True), o.diffusion(X, W))
+        assert np.array_equal(eng_mod.advection(X, W, U, V, params, strict=True), o.advection(X, W, u=U, v=V))
+        assert np.array_equal(eng_mod.circulation(X, W, U, V, params, strict=True), o.circulation(X, W, u=U, v=V))
+        # the FAST arithmetic must take the same clamp decisions except at exact ties
+        df = eng_mod.diffusion(X, W, params)
+        dr = o.diffusion(X, W)
+        assert np.abs(df.astype(np.float64) - dr).max() <= 4e-6 * max(np.abs(dr).max(), 1e-30) + np.spacing(np.abs(X).max())
+    o.close()
+
+
+def test_batch_independence(eng_mod, params, inputs, oracle_lib):
+    """Every batch item is an independent field: a batch of 37 ragged-count fields equals 37 single calls."""
+    o, Ta, q, wa, wv, u, v = _fields(inputs, oracle_lib, params, 200)
+    rng = np.random.default_rng(5)
+    X = np.stack([(Ta + np.float32(i)).astype(np.float32) for i in range(37)])
+    W = np.stack([wa if i % 2 else wv for i in range(37)])
+    d = eng_mod.diffusion(X, W, params, strict=True)
+    for i in (0, 1, 17, 36):
+        assert np.array_equal(d[i], o.diffusion(X[i], W[i]))
+    o.close()
+
+
+def test_diffusion_g384_strict(eng_mod, params, oracle_lib):
+    """384x192: every row sub-cycled, up to 225 sweeps in row 2, time2=1/ccx2=0 in the polar rows
+    (SURVEY.md App. B).  Oracle at the same grid."""
+    from greb_climate_model_amd import workload
+    inp = workload.make_inputs(384, 192)
+    o = oracle_lib.Oracle(inp, params)
+    g = o.grid()
+    assert g["dif_time2"][1] == 225 and g["dif_time2"][0] == 1 and g["dif_ccx2"][0] == 0.0
+    X = np.stack([inp.tclim[10], inp.qclim[400]])
+    W = np.stack([o.field(5), o.field(6)])
+    d = eng_mod.diffusion(X, W, params, strict=True)
+    assert np.array_equal(d[0], o.diffusion(X[0], W[0])) and np.array_equal(d[1], o.diffusion(X[1], W[1]))
+    a = eng_mod.advection(X, W, np.stack([inp.uclim[10]] * 2), np.stack([inp.vclim[10]] * 2), params, strict=True)
+    assert np.array_equal(a[0], o.advection(X[0], W[0], ityr=11))
+    o.close()
+
+
+# ------------------------------------------------------------------------------------ point physics
+@pytest.mark.parametrize("ityr", [1, 365, 730])
+def test_point_physics_vs_golden(eng_mod, params, routine_golden, inputs, ityr):
+    g = routine_golden
+    e = eng_mod.Engine(inputs, params)
+    in5 = np.stack([g[f"t{ityr}_in_{k}"] for k in ("Ts", "Ta", "To", "q", "cap_surf")])
+    out = e.point_physics(ityr, float(g[f"t{ityr}_co2"]), in5)
+    got = dict(zip(eng_mod.POINT_FIELDS, out))
+    exact = ("albedo", "sw", "LWsurf", "dq_rain", "Qlat_air", "dT_ocean", "dTo", "cap_surf_new")
+    for k in exact:  # no transcendental on the path: bit-exact
+        assert np.array_equal(got[k], g[f"t{ityr}_out_{k}"]), k
+    for k, ulps in (("em", 8), ("LWair_down", 8), ("Qlat", 64), ("dq_eva", 64)):
+        ref = g[f"t{ityr}_out_{k}"]
+        # Qlat = (q-qs)*...: cancellation amplifies the 1-ulp expf difference in qs
+        tol = ulps * np.spacing(np.abs(ref).max())
+        assert np.abs(got[k].astype(np.float64) - ref).max() <= tol, (k, np.abs(got[k] - ref).max(), tol)
+    e.close()
+
+
+# ------------------------------------------------------------------------------------ whole runs
+TOL = {"Tsurf": 1e-4, "Tair": 1e-4, "Tocean": 1e-4, "q": 2e-8, "albedo": 1e-6}
+
+
+def _check_run(mon, ref, label):
+    for i, (name, tol) in enumerate(TOL.items()):
+        r = rms(mon[:, i], ref[:, i])
+        print(f"{label:>8s} {name:7s} rms {r:.3e} max {np.abs(mon[:, i].astype(np.float64) - ref[:, i]).max():.3e} (tol {tol:.0e})")
+        assert r < tol, (label, name, r)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_run_short_vs_reference(eng_mod, params, inputs, strict):
+    """1+2-yr default namelist (2xCO2) vs the reference Fortran's output/scenario."""
+    g = load_golden("run_short_g96.npz")
+    e = eng_mod.Engine(inputs, params, strict=strict)
+    yf = e.flux_correction(1)
+    mon, yr = e.run(2, 680.0)
+    _check_run(mon[0].reshape(24, 5, 48, 96), g["monthly"], "strict" if strict else "fast")
+    yearly = np.concatenate([yf[0], yr[0]])
+    assert np.abs(yearly - g["yearly"]).max() < 2e-3, (yearly, g["yearly"])  # fp32 sum of 4608 values
+    st = e.state(0)
+    for i in range(4):
+        assert rms(st[i], g["final_state5"][i]) < (1e-3 if i < 3 else 1e-7)
+    assert np.isfinite(mon).all()
+    e.close()
+
+
+def test_ensemble_co2_sweep_vs_reference(eng_mod, params, inputs):
+    """BASELINE config 4 in miniature: 8 CO2 levels as 8 members of ONE engine (shared flux
+    correction, src/greb.f90:221), 1+3 yr, last December vs 8 separate reference runs."""
+    g = load_golden("ensemble_g96.npz")
+    e = eng_mod.Engine(inputs, params, n_members=8)
+    yf = e.flux_correction(1)
+    co2 = np.repeat(g["co2"][:, None], 3, axis=1)
+    mon, yr = e.run(3, co2)
+    for m in range(8):
+        _check_run(mon[m, 2, 11][None], g["december"][m][None], f"co2={g['co2'][m]:.0f}")
+        assert np.abs(np.concatenate([yf[m], yr[m]]) - g["yearly"][m]).max() < 2e-3
+    # members are independent: warmer with more CO2
+    assert np.all(np.diff(yr[:, -1, 0]) > 0)
+    e.close()
+
+
+def test_resume_and_corrections_roundtrip(eng_mod, params, inputs):
+    """run(2) == run(1)+run(1); corrections + state exported from one engine restart another
+     bit-identically."""
+    e = eng_mod.Engine(inputs, params)
+    e.flux_correction(1)
+    corr, st = e.get_corrections(0)
+    a1, _ = e.run(1, 680.0)
+    a2, _ = e.run(1, 680.0)
+    e2 = eng_mod.Engine(inputs, params)
+    e2.set_corrections(corr, st)
+    b, _ = e2.run(2, 680.0)
+    assert np.array_equal(b[0, 0], a1[0, 0]) and np.array_equal(b[0, 1], a2[0, 0])
+    e.close(); e2.close()
+
+
+def test_perturbed_physics_members(eng_mod, params, inputs, oracle_lib):
+    """BASELINE config 5 in miniature: per-member albedo/diffusivity overrides give each member
+    its own flux correction and sub-cycle tables; check two members against the oracle."""
+    from greb_climate_model_amd import abi
+    ov = [{}, {"kappa": 8.8e5, "a_cloud": 0.33}, {"da_ice": 0.27, "a_no_ice": 0.09}]
+    e = eng_mod.Engine(inputs, params, n_members=3, overrides=ov, strict=True)
+    e.flux_correction(1)
+    mon, _ = e.run(1, 680.0)
+    for m in (1, 2):
+        p = abi.default_params(ipx=95, ipy=38, **ov[m])
+        o = oracle_lib.Oracle(inputs, p)
+        o.flux_correction(1)
+        ref, _ = o.run(1, 680.0)
+        _check_run(mon[m].reshape(12, 5, 48, 96), ref.reshape(12, 5, 48, 96), f"member{m}")
+        o.close()
+    assert rms(mon[1], mon[0]) > 1e-3  # the perturbation does something
+    e.close()

@@ -1,0 +1,103 @@
+"""CPU: the oracle (oracle/greb_oracle.c) against the golden vectors minted from the compiled
+reference (tests/golden/make_golden.py).  Bit-exact: the oracle is the reference's arithmetic."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+
+def test_manifest_says_pinned():
+    m = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    for k in ("routine_g96", "run_short_g96", "run_default_g96"):
+        assert m["items"][k]["oracle_bit_identical"] is True
+
+
+def test_grid_tables_match_reference_probe(inputs, params, oracle_lib, routine_golden):
+    """sub-cycle tables at 96x48 (only the two polar rows iterate: 8 sweeps)."""
+    o = oracle_lib.Oracle(inputs, params)
+    g = o.grid()
+    for k, v in g.items():
+        assert np.array_equal(np.asarray(v), routine_golden["grid_" + k]), k
+    assert g["dif_time2"][0] == 8 and g["dif_time2"][47] == 8 and set(g["dif_time2"][1:47]) == {1}
+    assert set(g["adv_time2"]) == {1}
+    assert g["subcycled"].sum() == 20
+    assert abs(float(g["dif_ccy"]) - 8.281862e-3) < 1e-8 and abs(float(g["adv_ccy"]) - 2.1583668e-3) < 1e-9
+    o.close()
+
+
+@pytest.mark.parametrize("ityr", [1, 365, 730])
+def test_routines_bit_exact(inputs, params, oracle_lib, routine_golden, ityr):
+    g = routine_golden
+    o = oracle_lib.Oracle(inputs, params)
+    I = {k: g[f"t{ityr}_in_{k}"] for k in ("Ts", "Ta", "To", "q", "cap_surf")}
+    co2 = float(g[f"t{ityr}_co2"])
+    wa, wv = g["wz_air"], g["wz_vapor"]
+    assert np.array_equal(o.field(5), wa) and np.array_equal(o.field(6), wv)
+    got = {}
+    got["dif_Ta"] = o.diffusion(I["Ta"], wa); got["dif_q"] = o.diffusion(I["q"], wv)
+    got["adv_Ta"] = o.advection(I["Ta"], wa, ityr=ityr); got["adv_q"] = o.advection(I["q"], wv, ityr=ityr)
+    got["crc_Ta"] = o.circulation(I["Ta"], wa, ityr=ityr); got["crc_q"] = o.circulation(I["q"], wv, ityr=ityr)
+    got["sw"], got["albedo"] = o.swradiation(ityr, I["Ts"])
+    got["LWsurf"], got["LWair_up"], got["LWair_down"], got["em"] = o.lwradiation(ityr, I["Ts"], I["Ta"], I["q"], co2)
+    got["Qlat"], got["Qlat_air"], got["dq_eva"], got["dq_rain"] = o.hydro(ityr, I["Ts"], I["q"])
+    got["dT_ocean"], got["dTo"] = o.deep_ocean(ityr, I["Ts"], I["To"])
+    o.field(4)[:] = I["cap_surf"]
+    got["cap_surf_new"] = o.seaice(ityr, I["Ts"])
+    for k, v in got.items():
+        assert np.array_equal(v, g[f"t{ityr}_out_{k}"]), (ityr, k)
+    o.close()
+
+
+def test_run_short_bit_exact(inputs, params, oracle_lib):
+    """1+2-yr default-namelist run: all 24 months x 5 fields + the stdout scalars (src/greb.f90:954)."""
+    g = load_golden("run_short_g96.npz")
+    o = oracle_lib.Oracle(inputs, params)
+    yf = o.flux_correction(1)
+    mon, yr = o.run(2, 680.0)
+    assert np.array_equal(mon.reshape(24, 5, 48, 96), g["monthly"])
+    assert np.array_equal(np.concatenate([yf, yr]), g["yearly"])
+    assert np.array_equal(o.state5(), g["final_state5"])
+    o.close()
+
+
+def test_survey_toy_known_answers(inputs, params, oracle_lib):
+    """the deterministic toy fields and the values the reference returned for them."""
+    o = oracle_lib.Oracle(inputs, params)
+    i = np.arange(1, 97, dtype=np.int64)[None, :]
+    k = np.arange(1, 49, dtype=np.int64)[:, None]
+    f = np.float32
+    X = (f(250) + f(0.5) * ((7 * i + 3 * k) % 41).astype(f) - f(0.01) * ((k - 24) ** 2).astype(f)).astype(f)
+    zt = (f(100) * ((13 * i + 5 * k) % 29).astype(f) - f(800)).astype(f)
+    u = (((5 * i + k) % 17).astype(f) - f(8)).astype(f)
+    v = (f(0.25) * ((3 * i + 2 * k) % 13).astype(f) - f(1.5)).astype(f)
+    # wz_air = exp(-z_topo/z_air) as the survey's driver set it (glibc expf via the oracle's libm)
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.expf.restype = ctypes.c_float; libm.expf.argtypes = [ctypes.c_float]
+    wz = np.vectorize(lambda z: libm.expf(float(f(-z) / f(8400.0))), otypes=[f])(zt)
+    d = o.diffusion(X, wz); a = o.advection(X, wz, u=u, v=v); c = o.circulation(X, wz, u=u, v=v)
+    at = lambda A, ii, kk: float(A[kk - 1, ii - 1])
+    assert abs(at(d, 1, 1) - 4.36003351e+00) < 2e-6 and abs(at(d, 48, 24) - -1.71181947e-01) < 2e-7
+    assert abs(at(d, 96, 48) - -7.26046610e+00) < 2e-6
+    assert abs(at(a, 1, 1) - 3.52024406e-01) < 2e-7 and abs(at(a, 94, 3) - 7.67290071e-02) < 2e-8
+    assert abs(at(a, 96, 48) - -9.04053569e-01) < 2e-7
+    assert abs(at(c, 1, 1) - 5.19750977e+00) < 2e-5 and abs(at(c, 48, 24) - -3.26342773e+00) < 2e-5
+    assert abs(at(c, 96, 48) - -8.21525574e+00) < 2e-5
+    o.close()
+
+
+def test_run_default_statistics(inputs, params, oracle_lib):
+    """BASELINE config 1 (3+50 yr) is 55 s of CPU: check the first two scenario years against the
+    600-month statistics table instead of re-running all of it (make_golden.py did, bit for bit)."""
+    g = load_golden("run_default_g96.npz")
+    assert g["stats"].shape == (600, 5, 4) and g["yearly"].shape == (53, 2)
+    o = oracle_lib.Oracle(inputs, params)
+    o.flux_correction(3)
+    mon, yr = o.run(1, 680.0)
+    mon = mon.reshape(12, 5, 48, 96)
+    assert np.array_equal(mon[0], g["monthly_sel"][0]) and np.array_equal(mon[11], g["monthly_sel"][1])
+    assert np.allclose(mon.astype(np.float64).mean((2, 3)), g["stats"][:12, :, 0], rtol=0, atol=1e-9)
+    assert np.array_equal(yr[0], g["yearly"][3])
+    o.close()
