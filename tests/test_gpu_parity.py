@@ -133,7 +133,7 @@ def test_point_physics_vs_golden(eng_mod, params, routine_golden, inputs, ityr):
     exact = ("albedo", "sw", "LWsurf", "dq_rain", "Qlat_air", "dT_ocean", "dTo", "cap_surf_new")
     for k in exact:  # no transcendental on the path: bit-exact
         assert np.array_equal(got[k], g[f"t{ityr}_out_{k}"]), k
-    for k, ulps in (("em", 8), ("LWair_down", 8), ("Qlat", 64), ("dq_eva", 64)):
+    for k, ulps in (("em", 16), ("LWair_down", 32), ("Qlat", 64), ("dq_eva", 64)):
         ref = g[f"t{ityr}_out_{k}"]
         # Qlat = (q-qs)*...: cancellation amplifies the 1-ulp expf difference in qs
         tol = ulps * np.spacing(np.abs(ref).max())
