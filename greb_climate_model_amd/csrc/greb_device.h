@@ -36,16 +36,31 @@ struct f4 {
   float v[4];
 };
 
+// LDS pointers carry their address space explicitly so every access is a ds_read/ds_write
+// (a generic pointer costs a flat_load and, measured on MI355X, ~10x the latency).
+typedef __attribute__((address_space(3))) float lfloat;
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ f4 ld4(const float* p) {
-  const float4 a = *reinterpret_cast<const float4*>(p);
+  const vfloat4 a = *reinterpret_cast<const vfloat4*>(p);
+  return f4{{a.x, a.y, a.z, a.w}};
+}
+__device__ __forceinline__ f4 ld4(const lfloat* p) {
+  const vfloat4 a = *(const __attribute__((address_space(3))) vfloat4*)p;
   return f4{{a.x, a.y, a.z, a.w}};
 }
 __device__ __forceinline__ void st4(float* p, const f4& a) {
-  *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  vfloat4 v; v.x = a.v[0]; v.y = a.v[1]; v.z = a.v[2]; v.w = a.v[3];
+  *reinterpret_cast<vfloat4*>(p) = v;
+}
+__device__ __forceinline__ void st4(lfloat* p, const f4& a) {
+  vfloat4 v; v.x = a.v[0]; v.y = a.v[1]; v.z = a.v[2]; v.w = a.v[3];
+  *(__attribute__((address_space(3))) vfloat4*)p = v;
 }
 
 // window of 12 longitudes around quad q of a row (periodic, src/greb.f90:594,602,610,...)
-__device__ __forceinline__ void load_window(const float* row, int q, int nq, float t[12]) {
+template <typename P>
+__device__ __forceinline__ void load_window(P row, int q, int nq, float t[12]) {
   const int qm = (q == 0) ? nq - 1 : q - 1;
   const int qp = (q == nq - 1) ? 0 : q + 1;
   const f4 a = ld4(row + 4 * qm), b = ld4(row + 4 * q), c = ld4(row + 4 * qp);
@@ -229,6 +244,44 @@ __device__ __forceinline__ void lat_fast(const f4& T0, const f4& Tm2, const f4& 
     const float dm2 = wm2.v[i] * (t0 - Tm2.v[i]), dp2 = wp2.v[i] * (t0 - Tp2.v[i]);
     ddif[i] = ccy_dif * (gm1 + gp1);
     dadv[i] = ap * split_p(v[i]) * (dp2 - gp1) - am * split_m(v[i]) * (dm2 - gm1);
+  }
+}
+
+
+// ---- FAST pieces with pre-multiplied winds (the fused engine stages them in LDS once per model
+// step):  um = c*max(u,0), up = c*min(u,0) with c = ccx/3 (full rows) or ccx2/20 (sub-cycled rows);
+// vm = am*max(v,0), vp = ap*min(v,0) with am/ap of adv_lat_coef().
+__device__ __forceinline__ void adv_lon_full_pm(const Flux& f, const float T[12], const float w[12],
+                                                const float um[4], const float up[4], float d[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 + i;
+    const float em2 = w[c - 2] * (T[c] - T[c - 2]), ep2 = w[c + 2] * (T[c] - T[c + 2]);
+    d[i] = up[i] * (ep2 - f.Pp[c]) - um[i] * (f.Pm[c - 1] + em2);
+  }
+}
+__device__ __forceinline__ void adv_lon_sub_pm(const Flux& f, const float T[12], const float w[12],
+                                               const float um[4], const float up[4], bool last_quad, float d[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 + i;
+    const float am = 10.f * f.Pm[c - 1] + (4.f * f.Pm[c - 2] + f.Pm[c - 3]);
+    float ap = 10.f * f.Pp[c] + (4.f * f.Pp[c + 1] + f.Pp[c + 2]);
+    if (last_quad && i == 1) ap = 10.f * f.Pp[c] - w[c + 3] * (T[c + 1] - T[c + 3]); // :881
+    d[i] = -up[i] * ap - um[i] * am;
+  }
+}
+__device__ __forceinline__ void lat_pm(const f4& T0, const f4& Tm2, const f4& Tm1, const f4& Tp1, const f4& Tp2,
+                                       const f4& wm2, const f4& wm1, const f4& wp1, const f4& wp2,
+                                       const float vm[4], const float vp[4], float ccy_dif, float ddif[4],
+                                       float dadv[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t0 = T0.v[i];
+    const float gm1 = wm1.v[i] * (Tm1.v[i] - t0), gp1 = wp1.v[i] * (Tp1.v[i] - t0);
+    const float dm2 = wm2.v[i] * (t0 - Tm2.v[i]), dp2 = wp2.v[i] * (t0 - Tp2.v[i]);
+    ddif[i] = ccy_dif * (gm1 + gp1);
+    dadv[i] = vp[i] * (dp2 - gp1) - vm[i] * (dm2 - gm1);
   }
 }
 

@@ -213,6 +213,14 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
     return fail(nullptr, GREB_E_UNSUPPORTED,
                 "greb_engine_create: the fused member engine supports the 96x48 grid only in this build "
                 "(the batched diffusion/advection/circulation entry points take any grid)");
+  for (int m = 0; m < n_members; ++m) {
+    const float kap = (overrides && !std::isnan(overrides[m].kappa)) ? overrides[m].kappa : p->kappa;
+    RowTables t; compute_row_tables(*p, kap, nx, ny, t);
+    if (!member_layout_supported(t, nx, ny))
+      return fail(nullptr, GREB_E_UNSUPPORTED,
+                  "greb_engine_create: these pi/kappa/dt_crcl give a sub-cycling layout other than rows 1-10/39-48 "
+                  "with two iterating polar rows; the fused engine is specialised for that layout");
+  }
   if (p->ipx < 1 || p->ipx > nx || p->ipy < 1 || p->ipy > ny)
     return fail(nullptr, GREB_E_INVALID, "greb_engine_create: ipx/ipy outside the grid");
   greb_engine* e = new (std::nothrow) greb_engine();
@@ -496,7 +504,7 @@ static int adv_or_circ(bool circ, const greb_params* p, int nx, int ny, int batc
   HIP_TRY0(hipMemcpy(d.p, v, n * 4, hipMemcpyHostToDevice));
   if (circ) {
     HIP_TRY0(dev_alloc(&scr.p, 3 * n));
-    HIP_TRY0(launch_circulation(a.p, b.p, c.p, d.p, o.p, scr.p, tab_dev, nx, ny, batch, nsub_of(*p), strict != 0, nullptr));
+    HIP_TRY0(launch_circulation(a.p, b.p, c.p, d.p, o.p, scr.p, tab_dev, t, nx, ny, batch, nsub_of(*p), strict != 0, nullptr));
   } else {
     HIP_TRY0(launch_advection(a.p, b.p, c.p, d.p, o.p, tab_dev, nx, ny, batch, strict != 0, nullptr));
   }

@@ -41,8 +41,12 @@ struct MemberArgs {
   int ipx, ipy;          // 1-based
 };
 
-// fused engine, 96x48 only (whole member state resident in one CU's LDS)
+// fused engine (greb_member.hip): 96x48 with the default sub-cycling layout -- rows 0-9 and 38-47
+// sub-cycled, only the two polar rows iterating; whole member resident in one CU
+bool member_layout_supported(const RowTables& tab, int nx, int ny);
 hipError_t launch_member_kernel(const MemberArgs& a, int n_members, bool strict, hipStream_t s);
+hipError_t launch_circulation_g96(const float* X, const float* wz, const float* u, const float* v, float* dX,
+                                  const RowTables* tab_dev, int batch, int nsub, bool strict, hipStream_t s);
 
 // batched single-routine kernels, any grid with nx % 4 == 0, ny <= kMaxNy
 hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const RowTables* tab_dev, int nx,
@@ -51,8 +55,8 @@ hipError_t launch_advection(const float* T1, const float* wz, const float* u, co
                             const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s);
 // 24 sub-steps; 96x48 uses the fused LDS loop of the engine, other grids launch per sub-step
 hipError_t launch_circulation(const float* X, const float* wz, const float* u, const float* v, float* dX,
-                              float* scratch /* 3*batch*np */, const RowTables* tab_dev, int nx, int ny,
-                              int batch, int nsub, bool strict, hipStream_t s);
+                              float* scratch /* 3*batch*np */, const RowTables* tab_dev, const RowTables& tab_host,
+                              int nx, int ny, int batch, int nsub, bool strict, hipStream_t s);
 
 struct PointArgs {
   int nx, ny, np, ityr;

@@ -1,0 +1,267 @@
+// greb_stencil.h -- quad-level assembly of the stencil pieces (greb_device.h) shared by the
+// batched sweep kernels (greb_kernels.hip) and the fused member engine (greb_member.hip).
+#pragma once
+#include "greb_device.h"
+
+namespace greb {
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // order this wave's LDS writes before its later LDS reads (one wave owns a chain row);
+  // LDS instructions of one wave execute in issue order, so no s_barrier is needed
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A latitude band [r0, r1) of a field staged in LDS, row-major, nx floats per row.
+struct Rows {
+  const lfloat* base;
+  int r0, nx;
+  __device__ __forceinline__ const lfloat* row(int k) const { return base + (k - r0) * nx; }
+};
+
+struct QuadIn {
+  float T[12], w[12];
+  f4 T0, w0, Tm2, Tm1, Tp1, Tp2, wm2, wm1, wp1, wp2;
+};
+
+__device__ __forceinline__ f4 zero4() { return f4{{0.f, 0.f, 0.f, 0.f}}; }
+
+// the constants one latitude row needs (a register-resident slice of RowTables)
+struct RowK {
+  float dif_cc;  // dif_ccx (full-row branch) or dif_ccx2 (sub-cycled branch), :582 / :654
+  float adv_cc;  // adv_ccx or adv_ccx2, :753 / :840
+  float dif_ccy, adv_ccy;
+  int sub;       // !(dxlat(k) > 2.5e5)
+  int dif_time2, adv_time2;
+};
+__device__ __forceinline__ RowK row_consts(const RowTables& tab, int k) {
+  RowK r;
+  r.sub = tab.subcycled[k];
+  r.dif_cc = r.sub ? tab.dif_ccx2[k] : tab.dif_ccx[k];
+  r.adv_cc = r.sub ? tab.adv_ccx2[k] : tab.adv_ccx[k];
+  r.dif_ccy = tab.dif_ccy; r.adv_ccy = tab.adv_ccy;
+  r.dif_time2 = tab.dif_time2[k]; r.adv_time2 = tab.adv_time2[k];
+  return r;
+}
+
+// gather the neighbourhood of quad (k,q); rows outside [0,ny) get w = 0 and a clamped T row
+__device__ __forceinline__ void gather(const Rows& X, const Rows& W, int k, int q, int nq, int ny, bool lat2,
+                                       QuadIn& in) {
+  load_window(X.row(k), q, nq, in.T);
+  load_window(W.row(k), q, nq, in.w);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { in.T0.v[i] = in.T[4 + i]; in.w0.v[i] = in.w[4 + i]; }
+  const int km1 = k >= 1 ? k - 1 : k, kp1 = k <= ny - 2 ? k + 1 : k;
+  in.Tm1 = ld4(X.row(km1) + 4 * q); in.Tp1 = ld4(X.row(kp1) + 4 * q);
+  in.wm1 = k >= 1 ? ld4(W.row(km1) + 4 * q) : zero4();
+  in.wp1 = k <= ny - 2 ? ld4(W.row(kp1) + 4 * q) : zero4();
+  if (lat2) {
+    const int km2 = k >= 2 ? k - 2 : k, kp2 = k <= ny - 3 ? k + 2 : k;
+    in.Tm2 = ld4(X.row(km2) + 4 * q); in.Tp2 = ld4(X.row(kp2) + 4 * q);
+    in.wm2 = k >= 2 ? ld4(W.row(km2) + 4 * q) : zero4();
+    in.wp2 = k <= ny - 3 ? ld4(W.row(kp2) + 4 * q) : zero4();
+  } else {
+    in.Tm2 = in.T0; in.Tp2 = in.T0; in.wm2 = zero4(); in.wp2 = zero4();
+  }
+}
+
+// ---- one-sweep increments for a non-chain row (full-row branch, or sub-cycled with time2 == 1)
+template <bool STRICT>
+__device__ __forceinline__ void dif_quad(const QuadIn& in, const RowK& rk, int k, int ny, float out[4]) {
+  float dTx[4], dTy[4];
+  if (STRICT) {
+#pragma clang fp contract(off)
+    if (!rk.sub) {
+      dif_lon_strict(in.T, in.w, rk.dif_cc, dTx);
+    } else {
+      float T1h[4] = {in.T[4], in.T[5], in.T[6], in.T[7]};
+      dif_lon_strict(in.T, in.w, rk.dif_cc, dTx);
+      clamp_add(T1h, dTx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - in.T[4 + i]; // :718
+    }
+    dif_lat_strict(in.T0, in.Tm1, in.Tp1, in.wm1, in.wp1, rk.dif_ccy, k, ny, dTy);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = in.w0.v[i] * (dTx[i] + dTy[i]); // :721
+  } else {
+    Flux f;
+    make_flux(in.T, in.w, f);
+    if (!rk.sub) {
+      dif_lon_fast(f, rk.dif_cc * 0.05f, dTx);
+    } else {
+      float T1h[4] = {in.T[4], in.T[5], in.T[6], in.T[7]};
+      dif_lon_fast(f, rk.dif_cc * 0.05f, dTx);
+      clamp_add_fast(T1h, dTx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - in.T[4 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float g = in.wm1.v[i] * (in.Tm1.v[i] - in.T0.v[i]) + in.wp1.v[i] * (in.Tp1.v[i] - in.T0.v[i]);
+      out[i] = in.w0.v[i] * (dTx[i] + rk.dif_ccy * g);
+    }
+  }
+}
+
+__device__ __forceinline__ void adv_lat_coef(float adv_ccy, int k, int ny, float& am, float& ap) {
+  const float third = adv_ccy * (1.f / 3.f);
+  am = (k == 1) ? adv_ccy : third;      // :766-769
+  ap = (k == ny - 2) ? adv_ccy : third; // :784-787
+  if (k == 0) am = 0.f;
+  if (k == ny - 1) ap = 0.f;
+}
+
+template <bool STRICT>
+__device__ __forceinline__ void adv_quad(const QuadIn& in, const float u[4], const float v[4],
+                                         const RowK& rk, int k, int ny, bool last_quad, float out[4]) {
+  float dTx[4], dTy[4];
+  if (STRICT) {
+#pragma clang fp contract(off)
+    if (!rk.sub) {
+      adv_lon_full_strict(in.T, in.w, u, rk.adv_cc, dTx);
+    } else {
+      float T1h[4] = {in.T[4], in.T[5], in.T[6], in.T[7]};
+      adv_lon_sub_strict(in.T, in.w, u, rk.adv_cc, last_quad, dTx);
+      clamp_add(T1h, dTx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - in.T[4 + i]; // :910
+    }
+    adv_lat_strict(in.T0, in.Tm2, in.Tm1, in.Tp1, in.Tp2, in.wm2, in.wm1, in.wp1, in.wp2, v, rk.adv_ccy, k, ny, dTy);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = dTx[i] + dTy[i]; // :913
+  } else {
+    Flux f;
+    make_flux(in.T, in.w, f);
+    if (!rk.sub) {
+      adv_lon_full_fast(f, in.T, in.w, u, rk.adv_cc * (1.f / 3.f), dTx);
+    } else {
+      float T1h[4] = {in.T[4], in.T[5], in.T[6], in.T[7]};
+      adv_lon_sub_fast(f, in.T, in.w, u, rk.adv_cc * 0.05f, last_quad, dTx);
+      clamp_add_fast(T1h, dTx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - in.T[4 + i];
+    }
+    float am, ap, dd[4];
+    adv_lat_coef(rk.adv_ccy, k, ny, am, ap);
+    lat_fast(in.T0, in.Tm2, in.Tm1, in.Tp1, in.Tp2, in.wm2, in.wm1, in.wp1, in.wp2, v, 0.f, am, ap, dd, dTy);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = dTx[i] + dTy[i];
+  }
+}
+
+// ---- chain rows: rows whose sub-cycle count is > 1 (src/greb.f90:656-717, 842-909).  One wave
+// owns the row and iterates Jacobi sweeps through two LDS row buffers.
+enum ChainMode { kChainDif = 0, kChainAdv = 1, kChainFused = 2 };
+
+__host__ __device__ __forceinline__ bool is_chain_row(const RowTables& tab, int k, int mode) {
+  return (mode != kChainAdv && tab.dif_time2[k] > 1) || (mode != kChainDif && tab.adv_time2[k] > 1);
+}
+
+// time2 Jacobi sweeps of one row; result (T1h) is left in bufA.  urow: raw zonal wind of the row.
+template <bool STRICT>
+__device__ void chain_lon(const lfloat* Trow, const lfloat* wrow, const lfloat* urow, float cc, int time2,
+                          bool is_adv, int nq, int lane, lfloat* bufA, lfloat* bufB) {
+  for (int q = lane; q < nq; q += 64) st4(bufA + 4 * q, ld4(Trow + 4 * q));
+  wave_lds_sync();
+  lfloat* src = bufA;
+  lfloat* dst = bufB;
+  for (int tt = 0; tt < time2; ++tt) {
+    for (int q = lane; q < nq; q += 64) {
+      float T[12], w[12], d[4];
+      load_window((const lfloat*)src, q, nq, T);
+      load_window(wrow, q, nq, w);
+      float T1h[4] = {T[4], T[5], T[6], T[7]};
+      if (is_adv) {
+        const f4 uq = ld4(urow + 4 * q);
+        if (STRICT) {
+          adv_lon_sub_strict(T, w, uq.v, cc, q == nq - 1, d);
+          clamp_add(T1h, d);
+        } else {
+          Flux f; make_flux(T, w, f);
+          adv_lon_sub_fast(f, T, w, uq.v, cc * 0.05f, q == nq - 1, d);
+          clamp_add_fast(T1h, d);
+        }
+      } else {
+        if (STRICT) {
+          dif_lon_strict(T, w, cc, d);
+          clamp_add(T1h, d);
+        } else {
+          Flux f; make_flux(T, w, f);
+          dif_lon_fast(f, cc * 0.05f, d);
+          clamp_add_fast(T1h, d);
+        }
+      }
+      st4(dst + 4 * q, f4{{T1h[0], T1h[1], T1h[2], T1h[3]}});
+    }
+    wave_lds_sync();
+    lfloat* t = src; src = dst; dst = t;
+  }
+  if (src != bufA) { // odd sweep count: make the result land in the caller's bufA
+    for (int q = lane; q < nq; q += 64) st4(bufA + 4 * q, ld4((const lfloat*)src + 4 * q));
+    wave_lds_sync();
+  }
+}
+
+// complete update of one chain row by one wave.  out_row (any address space): the X_new row
+// (fused) or the dX row (dif / adv only).
+template <bool STRICT, typename OutP>
+__device__ void chain_row(const Rows& X, const Rows& W, const Rows& U, const Rows& V, const RowK& rk, int k,
+                          int nq, int ny, int lane, int mode, lfloat* scratch /* 4*nx */, OutP out_row) {
+  const int nx = 4 * nq;
+  lfloat* dA = scratch;          // diffusion T1h
+  lfloat* dB = scratch + nx;
+  lfloat* aA = scratch + 2 * nx; // advection T1h
+  lfloat* aB = scratch + 3 * nx;
+  const bool do_dif = mode != kChainAdv, do_adv = mode != kChainDif;
+  if (do_dif) chain_lon<STRICT>(X.row(k), W.row(k), nullptr, rk.dif_cc, rk.dif_time2, false, nq, lane, dA, dB);
+  if (do_adv) chain_lon<STRICT>(X.row(k), W.row(k), U.row(k), rk.adv_cc, rk.adv_time2, true, nq, lane, aA, aB);
+  for (int q = lane; q < nq; q += 64) {
+    QuadIn in;
+    gather(X, W, k, q, nq, ny, do_adv, in);
+    float r[4];
+    float dd[4] = {0, 0, 0, 0}, da[4] = {0, 0, 0, 0};
+    if (do_dif) {
+      const f4 t1 = ld4((const lfloat*)dA + 4 * q);
+      if (STRICT) {
+#pragma clang fp contract(off)
+        float dTy[4];
+        dif_lat_strict(in.T0, in.Tm1, in.Tp1, in.wm1, in.wp1, rk.dif_ccy, k, ny, dTy);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dd[i] = in.w0.v[i] * ((t1.v[i] - in.T0.v[i]) + dTy[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float g = in.wm1.v[i] * (in.Tm1.v[i] - in.T0.v[i]) + in.wp1.v[i] * (in.Tp1.v[i] - in.T0.v[i]);
+          dd[i] = in.w0.v[i] * ((t1.v[i] - in.T0.v[i]) + rk.dif_ccy * g);
+        }
+      }
+    }
+    if (do_adv) {
+      const f4 t2 = ld4((const lfloat*)aA + 4 * q);
+      const f4 vq = ld4(V.row(k) + 4 * q);
+      float dTy[4];
+      if (STRICT) {
+#pragma clang fp contract(off)
+        adv_lat_strict(in.T0, in.Tm2, in.Tm1, in.Tp1, in.Tp2, in.wm2, in.wm1, in.wp1, in.wp2, vq.v, rk.adv_ccy, k, ny, dTy);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) da[i] = (t2.v[i] - in.T0.v[i]) + dTy[i];
+      } else {
+        float am, ap, dummy[4];
+        adv_lat_coef(rk.adv_ccy, k, ny, am, ap);
+        lat_fast(in.T0, in.Tm2, in.Tm1, in.Tp1, in.Tp2, in.wm2, in.wm1, in.wp1, in.wp2, vq.v, 0.f, am, ap, dummy, dTy);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) da[i] = (t2.v[i] - in.T0.v[i]) + dTy[i];
+      }
+    }
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        r[i] = mode == kChainFused ? (in.T0.v[i] + dd[i]) + da[i] : (mode == kChainDif ? dd[i] : da[i]);
+    }
+    st4(out_row + 4 * q, f4{{r[0], r[1], r[2], r[3]}});
+  }
+}
+
+} // namespace greb
