@@ -10,6 +10,8 @@
 // Any grid with nx % 4 == 0: a workgroup stages a latitude band (+halo rows) of T and wz in LDS
 // with coalesced dwordx4 loads, sweeps it, and streams dX back as dwordx4.  No MFMA: there is no
 // dense contraction in this model.
+#include <cstdlib>
+
 #include "greb_kernels.h"
 #include "greb_stencil.h"
 
@@ -35,6 +37,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
   lfloat* sU = sW + nrows * nx; // advection only: band rows k0..k1
   lfloat* sV = sU + (MODE == kChainAdv ? (k1 - k0) * nx : 0);
   lfloat* scratch = sV + (MODE == kChainAdv ? (k1 - k0) * nx : 0); // [nwaves][4*nx]
+  lfloat* rowk = scratch + 4 * 4 * nx;                              // [ny][kRowKWords]
+  stage_row_consts(rowk, tab, ny);
   const size_t fo = (size_t)b * nx * ny;
   for (int i = threadIdx.x; i < nrows * nq; i += blockDim.x) {
     st4(sT + 4 * i, ld4(T1 + fo + (size_t)r0 * nx + 4 * i));
@@ -51,34 +55,163 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
   // chain rows: one wave each, round-robin
   int ci = 0;
   for (int k = k0; k < k1; ++k) {
-    if (!is_chain_row(tab, k, MODE)) continue;
+    const RowK rk = row_consts((const lfloat*)rowk, k);
+    if (!is_chain_row(rk, MODE)) continue;
     if ((ci++ % nwaves) == wave)
-      chain_row<STRICT>(X, W, U, V, row_consts(tab, k), k, nq, ny, lane, MODE, scratch + wave * 4 * nx, dX + fo + (size_t)k * nx);
+      chain_row<STRICT>(X, W, U, V, rk, k, nq, ny, lane, MODE, scratch + wave * 4 * nx, dX + fo + (size_t)k * nx);
   }
   // everything else: quads, all threads
   for (int i = threadIdx.x; i < (k1 - k0) * nq; i += blockDim.x) {
     const int k = k0 + i / nq, q = i % nq;
-    if (is_chain_row(tab, k, MODE)) continue;
+    const RowK rk = row_consts((const lfloat*)rowk, k);
+    if (is_chain_row(rk, MODE)) continue;
     QuadIn in;
     gather(X, W, k, q, nq, ny, MODE != kChainDif, in);
     float out[4];
     if (MODE == kChainDif) {
-      dif_quad<STRICT>(in, row_consts(tab, k), k, ny, out);
+      dif_quad<STRICT>(in, rk, k, ny, out);
     } else {
       const f4 uq = ld4(U.row(k) + 4 * q), vq = ld4(V.row(k) + 4 * q);
-      adv_quad<STRICT>(in, uq.v, vq.v, row_consts(tab, k), k, ny, q == nq - 1, out);
+      adv_quad<STRICT>(in, uq.v, vq.v, rk, k, ny, q == nq - 1, out);
     }
     st4(dX + fo + (size_t)k * nx + 4 * q, f4{{out[0], out[1], out[2], out[3]}});
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming form of the diffusion sweep for the 96x48 grid (whole field = 2 x 18 KB of LDS).
+//   * persistent workgroups walk the batch; while field b is swept out of LDS the loads of the
+//     workgroup's next field are already in flight into registers (9 dwordx4 per thread), so HBM
+//     latency overlaps the stencil instead of being paid once per field;
+//   * waves 0-2: 192 threads, one 4 lon x 6 lat tile each, sliding a 3-row window down the tile
+//     (6 ds_read_b128 per row instead of 14);
+//   * wave 3: the polar (chain) rows, two rows side by side in the wave (lanes 0-23 / 32-55), 8
+//     dependent Jacobi sweeps each (src/greb.f90:656-717);
+//   * the compute phase issues no global load (row constants are staged in LDS): s_waitcnt vmcnt
+//     is in-order, one table load would wait for the whole prefetch.
+// Traffic = the algorithmic 12 B/point exactly (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE).
+// ---------------------------------------------------------------------------------------------
+constexpr int kStreamThreads = 256;
+constexpr int kStreamQPT = 5; // quads per thread and array: covers 1280 quads (96x48 has 1152)
+constexpr int kTileRows = 6;
+
+template <bool STRICT, int NX_, int NY_>
+__global__ __launch_bounds__(kStreamThreads) void diffusion_stream_kernel(const float* __restrict__ T1,
+                                                                          const float* __restrict__ wz,
+                                                                          float* __restrict__ dX,
+                                                                          const RowTables* __restrict__ tabp,
+                                                                          int batch, int dbg) {
+  constexpr int nx = NX_, ny = NY_, nq = NX_ / 4, nquad = NY_ * nq;
+  static_assert(NY_ % kTileRows == 0 && nq * (NY_ / kTileRows) == 192, "tile map is for 96x48");
+  extern __shared__ __align__(16) float lds_raw[];
+  lfloat* lds = (lfloat*)lds_raw;
+  lfloat* sT = lds;
+  lfloat* sW = sT + ny * nx;
+  lfloat* scratch = sW + ny * nx;      // [2 halves][4*nx]
+  lfloat* rowk = scratch + 2 * 4 * nx; // [ny][kRowKWords]
+  lfloat* chainlist = rowk + ny * kRowKWords; // [ny] row indices of the chain rows
+  stage_row_consts(rowk, *tabp, ny);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int nchain = 0; // uniform: every thread scans the (global, cached) table once
+  for (int kk = 0; kk < ny; ++kk)
+    if (is_chain_row(*tabp, kk, kChainDif)) {
+      if (tid == 0) chainlist[nchain] = __int_as_float(kk);
+      ++nchain;
+    }
+  const Rows X{sT, 0, nx}, W{sW, 0, nx};
+  f4 rT[kStreamQPT], rW[kStreamQPT];
+  int b = blockIdx.x;
+  if (b < batch) {
+    const size_t fo = (size_t)b * nx * ny;
+#pragma unroll
+    for (int j = 0; j < kStreamQPT; ++j) {
+      const int i = tid + j * kStreamThreads;
+      if (i < nquad) { rT[j] = ld4(T1 + fo + 4 * i); rW[j] = ld4(wz + fo + 4 * i); }
+    }
+  }
+  // static role data
+  const int tq = tid % nq, tg = tid / nq;          // bulk: quad column, row group (tid < 192)
+  const int k0 = tg * kTileRows;
+  const int qm = tq == 0 ? nq - 1 : tq - 1, qp = tq == nq - 1 ? 0 : tq + 1;
+  for (; b < batch; b += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < kStreamQPT; ++j) {
+      const int i = tid + j * kStreamThreads;
+      if (i < nquad) { st4(sT + 4 * i, rT[j]); st4(sW + 4 * i, rW[j]); }
+    }
+    __syncthreads();
+    const int nb = b + gridDim.x;
+    if (nb < batch) { // prefetch the next field; consumed at the top of the next iteration
+      const size_t fo = (size_t)nb * nx * ny;
+#pragma unroll
+      for (int j = 0; j < kStreamQPT; ++j) {
+        const int i = tid + j * kStreamThreads;
+        if (i < nquad) { rT[j] = ld4(T1 + fo + 4 * i); rW[j] = ld4(wz + fo + 4 * i); }
+      }
+    }
+    float* out = dX + (size_t)b * nx * ny;
+    if (wave == 3) {
+      // chain rows, two at a time (lanes 0-31 / 32-63); the list was built once at kernel start
+      if (!(dbg & 4)) {
+        const int half = lane >> 5, ql = lane & 31;
+        for (int c = 0; c < nchain; c += 2) {
+          const int ci = c + half;
+          if (ci < nchain) {
+            const int k = __float_as_int(chainlist[ci]);
+            chain_row<STRICT>(X, W, X, X, row_consts((const lfloat*)rowk, k), k, nq, ny, ql, kChainDif,
+                              scratch + half * 4 * nx, out + (size_t)k * nx);
+          }
+        }
+      }
+    } else if (!(dbg & 1)) {
+      // bulk tile: rows k0 .. k0+5, sliding window (T and w): C[0..2] = rows k-1, k, k+1
+      f4 CT[3], CW[3];
+      {
+        const int km = k0 > 0 ? k0 - 1 : 0;
+        CT[0] = ld4(sT + km * nx + 4 * tq); CW[0] = k0 > 0 ? ld4(sW + km * nx + 4 * tq) : zero4();
+        CT[1] = ld4(sT + k0 * nx + 4 * tq); CW[1] = ld4(sW + k0 * nx + 4 * tq);
+      }
+#pragma unroll
+      for (int r = 0; r < kTileRows; ++r) {
+        const int k = k0 + r;
+        const int kp = k < ny - 1 ? k + 1 : k;
+        CT[2] = ld4(sT + kp * nx + 4 * tq);
+        CW[2] = k < ny - 1 ? ld4(sW + kp * nx + 4 * tq) : zero4();
+        const RowK rk = row_consts((const lfloat*)rowk, k);
+        if (!is_chain_row(rk, kChainDif)) {
+          const f4 LT = ld4(sT + k * nx + 4 * qm), RT = ld4(sT + k * nx + 4 * qp);
+          const f4 LW = ld4(sW + k * nx + 4 * qm), RW = ld4(sW + k * nx + 4 * qp);
+          QuadIn in;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            in.T[j] = LT.v[j]; in.T[4 + j] = CT[1].v[j]; in.T[8 + j] = RT.v[j];
+            in.w[j] = LW.v[j]; in.w[4 + j] = CW[1].v[j]; in.w[8 + j] = RW.v[j];
+          }
+          in.T0 = CT[1]; in.w0 = CW[1];
+          in.Tm1 = CT[0]; in.Tp1 = CT[2]; in.wm1 = CW[0]; in.wp1 = CW[2];
+          in.Tm2 = CT[1]; in.Tp2 = CT[1]; in.wm2 = zero4(); in.wp2 = zero4();
+          float o[4];
+          dif_quad<STRICT>(in, rk, k, ny, o);
+          st4(out + (size_t)k * nx + 4 * tq, f4{{o[0], o[1], o[2], o[3]}});
+        }
+        CT[0] = CT[1]; CW[0] = CW[1]; CT[1] = CT[2]; CW[1] = CW[2];
+      }
+    }
+    __syncthreads(); // everyone is done reading LDS before the next field overwrites it
+  }
+}
+
+static size_t stream_lds_bytes(int nx, int ny) { return (size_t)(2 * nx * ny + 2 * 4 * nx + ny * kRowKWords + ny) * sizeof(float); }
+static bool stream_fits(int nx, int ny) { return nx == 96 && ny == 48; }
+
 static size_t sweep_lds_bytes(int nx, int rows, int halo, int extra_fields) {
-  return (size_t)(((rows + 2 * halo) * 2 + rows * extra_fields) * nx + 4 * 4 * nx) * sizeof(float);
+  return (size_t)(((rows + 2 * halo) * 2 + rows * extra_fields) * nx + 4 * 4 * nx + kMaxNy * kRowKWords) * sizeof(float);
 }
 static int pick_band_rows(int nx, int ny, int halo, int extra_fields) {
   // whole field per workgroup when it fits ~44 KB (3+ workgroups share a CU's 160 KB); wide
   // grids get latitude bands of <= 64 KB
-  const size_t limit = nx <= 128 ? 44 * 1024 : 64 * 1024;
+  size_t limit = nx <= 128 ? 44 * 1024 : 64 * 1024;
+  if (const char* e = getenv("GREB_BAND_LIMIT_KB")) limit = (size_t)atoi(e) * 1024; // tuning experiments
   int rows = ny;
   while (rows > 2 && sweep_lds_bytes(nx, rows, halo, extra_fields) > limit) rows = (rows + 1) / 2;
   return rows;
@@ -103,6 +236,21 @@ static hipError_t launch_sweep(const float* T1, const float* wz, const float* u,
 
 hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const RowTables* tab_dev, int nx,
                             int ny, int batch, bool strict, hipStream_t s) {
+  static const bool no_stream = getenv("GREB_NO_STREAM") != nullptr; // A/B experiments
+  if (stream_fits(nx, ny) && !no_stream) {
+    const size_t lds = stream_lds_bytes(nx, ny);
+    auto kern = strict ? diffusion_stream_kernel<true, 96, 48> : diffusion_stream_kernel<false, 96, 48>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    static int wg_per_cu = getenv("GREB_STREAM_WGS") ? atoi(getenv("GREB_STREAM_WGS")) : 3;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = batch < cus * wg_per_cu ? batch : cus * wg_per_cu;
+    static const int dbg = getenv("GREB_DEBUG_SKIP") ? atoi(getenv("GREB_DEBUG_SKIP")) : 0; // timing experiments
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kStreamThreads), lds, s, T1, wz, dX, tab_dev, batch, dbg);
+    return hipGetLastError();
+  }
   return launch_sweep<kChainDif>(T1, wz, nullptr, nullptr, dX, tab_dev, nx, ny, batch, strict, s);
 }
 hipError_t launch_advection(const float* T1, const float* wz, const float* u, const float* v, float* dX,

@@ -22,6 +22,8 @@
 // Every sub-step a bulk thread slides a 5-row window down its tile for each tracer, reading T and
 // w as dwordx4 from LDS, computes X_new = (X + dX_diffuse) + dX_advec and writes the other
 // buffer; one s_barrier per sub-step.
+#include <cstdlib>
+
 #include "greb_kernels.h"
 #include "greb_stencil.h"
 
@@ -233,10 +235,11 @@ struct Circ {
     }
   }
 
-  __device__ __forceinline__ void substep(lfloat* lds, int cur) {
-    if (role.kind == 0) tile_substep<STRICT, 3>(lds, cur, role.k0, role.tx, tk);
-    else if (role.kind == 1) tile_substep<STRICT, 4>(lds, cur, role.k0, role.tx, tk);
-    else if (role.kind == 2) chain_substep<STRICT>(lds, cur, role.pole, tk.rk[0]);
+  // dbg: timing experiments only (tools/microbench_circ.py): bit0/1/2 skip sub / full / chain work
+  __device__ __forceinline__ void substep(lfloat* lds, int cur, int dbg = 0) {
+    if (role.kind == 0) { if (!(dbg & 1)) tile_substep<STRICT, 3>(lds, cur, role.k0, role.tx, tk); }
+    else if (role.kind == 1) { if (!(dbg & 2)) tile_substep<STRICT, 4>(lds, cur, role.k0, role.tx, tk); }
+    else if (role.kind == 2) { if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, role.pole, tk.rk[0]); }
   }
 };
 
@@ -250,7 +253,8 @@ __global__ __launch_bounds__(kThreads) void circulation_g96_kernel(const float* 
                                                                    const float* __restrict__ ug,
                                                                    const float* __restrict__ vg,
                                                                    float* __restrict__ dX,
-                                                                   const RowTables* __restrict__ tab, int nsub) {
+                                                                   const RowTables* __restrict__ tab, int nsub,
+                                                                   int dbg) {
   extern __shared__ __align__(16) float lds_raw[];
   lfloat* lds = (lfloat*)lds_raw;
   const size_t fo = (size_t)blockIdx.x * NP;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void circulation_g96_kernel(const float* 
   int cur = 0;
 #pragma unroll 1
   for (int tt = 0; tt < nsub; ++tt) {
-    c.substep(lds, cur);
+    c.substep(lds, cur, dbg);
     __syncthreads();
     cur ^= 1;
   }
@@ -281,7 +285,8 @@ hipError_t launch_circulation_g96(const float* X, const float* wz, const float* 
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(batch), dim3(kThreads), kLdsBytes, s, X, wz, u, v, dX, tab_dev, nsub);
+  const char* env = getenv("GREB_DEBUG_SKIP"); // timing experiments only
+  hipLaunchKernelGGL(kern, dim3(batch), dim3(kThreads), kLdsBytes, s, X, wz, u, v, dX, tab_dev, nsub, env ? atoi(env) : 0);
   return hipGetLastError();
 }
 
