@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -146,6 +147,7 @@ MemberArgs base_args(greb_engine* e) {
   a.state = e->state; a.acc = e->acc; a.corr = e->corr; a.corr_index = e->corr_index;
   a.tabs = e->tabs; a.tab_index = e->tab_index; a.phys = e->phys;
   a.nsub = nsub_of(e->p);
+  if (const char* ns = getenv("GREB_DEBUG_NSUB")) a.nsub = atoi(ns); // timing experiments only
   a.co2_flux = e->p.co2_flux;
   a.ipx = e->p.ipx; a.ipy = e->p.ipy;
   return a;
