@@ -62,7 +62,8 @@ def main():
     params.ipx, params.ipy = 95, 38
 
     # ---------------- ensemble: global member g = rank*M + i, CO2 swept over 280..1120 ppm
-    levels = ensemble.co2_sweep(world * M)[rank * M:(rank + 1) * M]
+    ids = ensemble.partition(world * M, world, rank)  # contiguous block of M members per rank
+    levels = ensemble.co2_sweep(world * M)[ids]
     eng = engine.Engine(inp, params, n_members=M, device=local_rank, strict=args.strict)
     eng.flux_correction(1)  # shared by all members (same physics): one member integrated, state broadcast
     np_ = eng.np
@@ -72,8 +73,6 @@ def main():
         eng.run(W, np.repeat(levels[:, None], W, 1), monthly_dev_ptr=wbuf.data_ptr())
         del wbuf
     gathered = None
-    if world > 1 and rank == 0:
-        gathered = [torch.empty_like(monthly) for _ in range(world)]
 
     def barrier():
         torch.cuda.synchronize()
@@ -84,7 +83,7 @@ def main():
     t0 = time.perf_counter()
     eng.run(K, np.repeat(levels[:, None], K, 1), monthly_dev_ptr=monthly.data_ptr())
     if world > 1:
-        dist.gather(monthly, gathered, dst=0)  # RCCL over xGMI: the monthly-mean gather
+        gathered = ensemble.gather_monthly(monthly, world * M)  # RCCL over xGMI: the monthly-mean gather
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -93,7 +92,7 @@ def main():
         dt = float(tmax.item())
     value = world * M * K / dt
 
-    finite = bool(torch.isfinite(monthly).all().item())
+    finite = bool(torch.isfinite(monthly if gathered is None else gathered).all().item())
     tmean = float(monthly[:, -1, :, 0].mean().item())
 
     extra = {}

@@ -1,0 +1,256 @@
+! greb_host.f90 -- thin Fortran host of the MI355X GREB engine.
+!
+! Keeps the reference's user-facing conventions and hands the time loops to the C-ABI engine
+! (include/greb_engine.h) through iso_c_binding:
+!   * command line: ./greb_host [namelist]            (reference: src/greb.f90:1032-1038)
+!   * namelist groups physics_par / numerics_par / diagnostics_par / co2_par with the
+!     reference's names and defaults                  (src/greb.f90:49-55,68-104,128-134,152-156;
+!                                                       doc/namelist.md)
+!   * the ten raw fp32 direct-access files under input/ (src/greb.f90:1018-1027,1073-1085)
+!   * co2_ppm padding rule                             (src/greb.f90:1053-1061)
+!   * output file name <output_file>[_<ens_id>], 5 direct-access records per month in the order
+!     Tsurf, Tair, Tocean, q, albedo                   (src/greb.f90:1064-1068,174,978-982)
+!   * the console trace                                (src/greb.f90:219,224-225,941,954,1070)
+! Control crosses into the engine twice per run (flux-correction phase, scenario phase); the
+! derived fields of greb_model's preamble are computed by the engine's create().
+! An optional fifth group &ENGINE_PAR (strict, device) selects reference-order arithmetic / GPU.
+module greb_c_api
+  use iso_c_binding
+  implicit none
+
+  type, bind(C) :: greb_params
+     real(c_float) :: pi, sig, rho_ocean, rho_land, rho_air, cp_ocean, cp_land, cp_air, eps
+     real(c_float) :: d_ocean, d_land, d_air, ct_sens, da_ice, a_no_ice, a_cloud
+     real(c_float) :: Tl_ice1, Tl_ice2, To_ice1, To_ice2
+     real(c_float) :: co_turb, kappa, ce, cq_latent, cq_rain, z_air, z_vapor, r_qviwv
+     real(c_float) :: p_emi(10)
+     real(c_float) :: co2_flux
+     integer(c_int32_t) :: ipx, ipy, year0, dt, dt_crcl
+  end type greb_params
+
+  type, bind(C) :: greb_fields
+     type(c_ptr) :: z_topo, glacier, sw_solar, tclim, qclim, uclim, vclim, mldclim, cldclim, swetclim
+  end type greb_fields
+
+  interface
+     subroutine greb_params_default(p) bind(C, name="greb_params_default")
+       import :: greb_params
+       type(greb_params), intent(out) :: p
+     end subroutine
+     integer(c_int) function greb_engine_create(p, nx, ny, f, n_members, overrides, device, flags, eng) &
+          bind(C, name="greb_engine_create")
+       import :: greb_params, greb_fields, c_int, c_ptr
+       type(greb_params), intent(in) :: p
+       integer(c_int), value :: nx, ny, n_members, device, flags
+       type(greb_fields), intent(in) :: f
+       type(c_ptr), value :: overrides
+       type(c_ptr), intent(out) :: eng
+     end function
+     integer(c_int) function greb_engine_flux_correction(eng, years, yearly) bind(C, name="greb_engine_flux_correction")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: eng
+       integer(c_int), value :: years
+       real(c_float), intent(out) :: yearly(*)
+     end function
+     integer(c_int) function greb_engine_run(eng, years, co2_ppm, monthly, yearly, run_flags) bind(C, name="greb_engine_run")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: eng
+       integer(c_int), value :: years, run_flags
+       real(c_float), intent(in) :: co2_ppm(*)
+       real(c_float), intent(out) :: monthly(*), yearly(*)
+     end function
+     integer(c_int) function greb_engine_destroy(eng) bind(C, name="greb_engine_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: eng
+     end function
+     function greb_engine_last_error(eng) bind(C, name="greb_engine_last_error") result(msg)
+       import :: c_ptr
+       type(c_ptr), value :: eng
+       type(c_ptr) :: msg
+     end function
+  end interface
+contains
+  subroutine engine_check(rc, eng, what)
+    integer(c_int), intent(in) :: rc
+    type(c_ptr), intent(in) :: eng
+    character(*), intent(in) :: what
+    character(kind=c_char), pointer :: cmsg(:)
+    type(c_ptr) :: p
+    integer :: i
+    if (rc == 0) return
+    write(*, '(a,a,a,i0)') 'greb_host: ', what, ' failed, code ', rc
+    p = greb_engine_last_error(eng)
+    if (c_associated(p)) then
+       call c_f_pointer(p, cmsg, [512])
+       do i = 1, 512
+          if (cmsg(i) == c_null_char) exit
+          write(*, '(a)', advance='no') cmsg(i)
+       end do
+       write(*, *)
+    end if
+    error stop 1
+  end subroutine
+end module greb_c_api
+
+program greb_host
+  use iso_c_binding
+  use greb_c_api
+  implicit none
+
+  integer, parameter :: nx = 96, ny = 48, nstep = 730
+  ! ---- namelist variables under the reference's names
+  real :: pi, sig, rho_ocean, rho_land, rho_air, cp_ocean, cp_land, cp_air, eps
+  real :: d_ocean, d_land, d_air, ct_sens, da_ice, a_no_ice, a_cloud
+  real :: Tl_ice1, Tl_ice2, To_ice1, To_ice2
+  real :: co_turb, kappa, ce, cq_latent, cq_rain, z_air, z_vapor, r_qviwv
+  real :: p_emi(10)
+  real :: co2_flux
+  real, allocatable :: co2_ppm(:)
+  integer :: ipx, ipy, time_flux, time_scnr, year0
+  character(len=120) :: output_file
+  character(len=10)  :: ens_id
+  logical :: strict
+  integer :: device
+  namelist / physics_par / pi, sig, rho_ocean, rho_land, rho_air, cp_ocean, cp_land, cp_air, eps, &
+       d_ocean, d_land, d_air, ct_sens, da_ice, a_no_ice, a_cloud, Tl_ice1, Tl_ice2, To_ice1, To_ice2, &
+       co_turb, kappa, ce, cq_latent, cq_rain, z_air, z_vapor, r_qviwv, p_emi
+  namelist / numerics_par / ipx, ipy, time_flux, time_scnr, year0
+  namelist / diagnostics_par / output_file, ens_id
+  namelist / co2_par / co2_ppm, co2_flux
+  namelist / engine_par / strict, device
+
+  type(greb_params) :: prm
+  type(greb_fields) :: fld
+  type(c_ptr) :: eng
+  real(c_float), allocatable, target :: z_topo(:,:), glacier(:,:), sw_solar(:,:)
+  real(c_float), allocatable, target :: tclim(:,:,:), qclim(:,:,:), uclim(:,:,:), vclim(:,:,:), &
+       mldclim(:,:,:), cldclim(:,:,:), swetclim(:,:,:)
+  real(c_float), allocatable :: monthly(:), yearly(:), yflux(:)
+  character(len=256) :: nml_file
+  character(len=131) :: out_full
+  integer :: n, i, irec, nrec, ios, nargs
+  integer(c_int) :: rc, flags
+  integer(8) :: off
+  real :: year
+
+  ! ---- defaults: the engine's copy of the reference defaults, then the namelist on top
+  call greb_params_default(prm)
+  pi = prm%pi; sig = prm%sig; rho_ocean = prm%rho_ocean; rho_land = prm%rho_land; rho_air = prm%rho_air
+  cp_ocean = prm%cp_ocean; cp_land = prm%cp_land; cp_air = prm%cp_air; eps = prm%eps
+  d_ocean = prm%d_ocean; d_land = prm%d_land; d_air = prm%d_air; ct_sens = prm%ct_sens
+  da_ice = prm%da_ice; a_no_ice = prm%a_no_ice; a_cloud = prm%a_cloud
+  Tl_ice1 = prm%Tl_ice1; Tl_ice2 = prm%Tl_ice2; To_ice1 = prm%To_ice1; To_ice2 = prm%To_ice2
+  co_turb = prm%co_turb; kappa = prm%kappa; ce = prm%ce; cq_latent = prm%cq_latent; cq_rain = prm%cq_rain
+  z_air = prm%z_air; z_vapor = prm%z_vapor; r_qviwv = prm%r_qviwv; p_emi = prm%p_emi
+  co2_flux = prm%co2_flux
+  ipx = 1; ipy = 1; time_flux = 0; time_scnr = 0; year0 = 1940
+  output_file = 'output/scenario'; ens_id = ''
+  strict = .false.; device = 0
+
+  nargs = command_argument_count()
+  nml_file = 'namelist'
+  if (nargs >= 1) call get_command_argument(1, nml_file)
+  open(10, file=trim(nml_file), action='read', status='old')
+  read(10, nml=physics_par)
+  read(10, nml=numerics_par)
+  read(10, nml=diagnostics_par)
+  allocate(co2_ppm(max(time_scnr, 1)))
+  co2_ppm = -1.
+  read(10, nml=co2_par)
+  read(10, nml=engine_par, iostat=ios)   ! optional group
+  close(10)
+
+  ! a series shorter than the run is continued with its last value; none at all means 2xCO2
+  if (co2_ppm(1) == -1.) co2_ppm(1) = 680.
+  do i = 2, time_scnr
+     if (co2_ppm(i) < 0.) co2_ppm(i) = co2_ppm(i-1)
+  end do
+
+  if (len_trim(ens_id) == 0) then
+     out_full = trim(output_file)
+  else
+     out_full = trim(output_file) // '_' // trim(ens_id)
+  end if
+
+  print*,'% diagonstic point lat/lon: ',3.75*ipy-90, 3.75*ipx
+
+  ! ---- boundary data
+  allocate(z_topo(nx,ny), glacier(nx,ny), sw_solar(ny,nstep))
+  allocate(tclim(nx,ny,nstep), qclim(nx,ny,nstep), uclim(nx,ny,nstep), vclim(nx,ny,nstep))
+  allocate(mldclim(nx,ny,nstep), cldclim(nx,ny,nstep), swetclim(nx,ny,nstep))
+  call read_records('input/topography', z_topo, 1)
+  call read_records('input/glacier.masks', glacier, 1)
+  open(15, file='input/solar.radiation', access='direct', form='unformatted', recl=4*ny*nstep, status='old')
+  read(15, rec=1) sw_solar
+  close(15)
+  call read_records('input/tsurf', tclim, nstep)
+  call read_records('input/vapor', qclim, nstep)
+  call read_records('input/soil.moisture', swetclim, nstep)
+  call read_records('input/zonal.wind', uclim, nstep)
+  call read_records('input/meridional.wind', vclim, nstep)
+  call read_records('input/ocean.mld', mldclim, nstep)
+  call read_records('input/cloud.cover', cldclim, nstep)
+
+  ! ---- hand everything to the engine
+  prm%pi = pi; prm%sig = sig; prm%rho_ocean = rho_ocean; prm%rho_land = rho_land; prm%rho_air = rho_air
+  prm%cp_ocean = cp_ocean; prm%cp_land = cp_land; prm%cp_air = cp_air; prm%eps = eps
+  prm%d_ocean = d_ocean; prm%d_land = d_land; prm%d_air = d_air; prm%ct_sens = ct_sens
+  prm%da_ice = da_ice; prm%a_no_ice = a_no_ice; prm%a_cloud = a_cloud
+  prm%Tl_ice1 = Tl_ice1; prm%Tl_ice2 = Tl_ice2; prm%To_ice1 = To_ice1; prm%To_ice2 = To_ice2
+  prm%co_turb = co_turb; prm%kappa = kappa; prm%ce = ce; prm%cq_latent = cq_latent; prm%cq_rain = cq_rain
+  prm%z_air = z_air; prm%z_vapor = z_vapor; prm%r_qviwv = r_qviwv; prm%p_emi = p_emi
+  prm%co2_flux = co2_flux
+  prm%ipx = ipx; prm%ipy = ipy; prm%year0 = year0
+  fld%z_topo = c_loc(z_topo); fld%glacier = c_loc(glacier); fld%sw_solar = c_loc(sw_solar)
+  fld%tclim = c_loc(tclim); fld%qclim = c_loc(qclim); fld%uclim = c_loc(uclim); fld%vclim = c_loc(vclim)
+  fld%mldclim = c_loc(mldclim); fld%cldclim = c_loc(cldclim); fld%swetclim = c_loc(swetclim)
+  flags = 0
+  if (strict) flags = 1
+  eng = c_null_ptr
+  rc = greb_engine_create(prm, nx, ny, fld, 1, c_null_ptr, int(device, c_int), flags, eng)
+  call engine_check(rc, eng, 'greb_engine_create')
+
+  print*,'% FLUX CORRECTION RUN; years = ', time_flux, ' co2 = ', co2_flux
+  allocate(yflux(2*max(time_flux,1)))
+  rc = greb_engine_flux_correction(eng, int(time_flux, c_int), yflux)
+  call engine_check(rc, eng, 'greb_engine_flux_correction')
+  if (time_flux > 0) print *, 'console output: year, co2, global avg temp, avg temp for ipx/ipy'
+  do n = 1, time_flux
+     print *, 0.0, co2_flux, yflux(2*n-1), yflux(2*n)
+  end do
+
+  print*,'% MODEL RUN; years = ', time_scnr
+  print*,'% saving output in file ', out_full
+  if (time_scnr > 0) then
+     nrec = time_scnr*12*5
+     allocate(monthly(int(nrec,8)*nx*ny), yearly(2*time_scnr))
+     rc = greb_engine_run(eng, int(time_scnr, c_int), co2_ppm, monthly, yearly, 0_c_int)
+     call engine_check(rc, eng, 'greb_engine_run')
+     print *, 'console output: year, co2, global avg temp, avg temp for ipx/ipy'
+     year = year0
+     do n = 1, time_scnr
+        print *, year, co2_ppm(n), yearly(2*n-1), yearly(2*n)
+        year = year + 1
+     end do
+     open(22, file=out_full, access='direct', form='unformatted', recl=4*nx*ny)
+     do irec = 1, nrec
+        off = int(irec-1, 8)*nx*ny
+        write(22, rec=irec) monthly(off+1:off+nx*ny)
+     end do
+     close(22)
+  end if
+  rc = greb_engine_destroy(eng)
+
+contains
+  subroutine read_records(fname, a, nrecs)
+    character(*), intent(in) :: fname
+    integer, intent(in) :: nrecs
+    real(c_float), intent(out) :: a(nx, ny, *)
+    integer :: r, u
+    open(newunit=u, file=fname, access='direct', form='unformatted', recl=4*nx*ny, status='old')
+    do r = 1, nrecs
+       read(u, rec=r) a(:, :, r)
+    end do
+    close(u)
+  end subroutine
+end program greb_host
