@@ -105,25 +105,25 @@ __device__ __forceinline__ void adv_lon_full_strict(const float T[12], const flo
   }
 }
 
-// src/greb.f90:845-851 (+ the :881 index bug for j = xdim-2): sub-cycled advection increment
+// src/greb.f90:845-851 (+ the :881 index bug for j = xdim-2): sub-cycled advection increment of
+// the point at window index c; bug = this is longitude xdim-2 (1-based), whose "+2" neighbour
+// aliases the "+1" one (jp2 = xdim-1)
+__device__ __forceinline__ float adv_lon_sub_point_strict(const float* T, const float* w, float u, float ccx2,
+                                                          int c, bool bug) {
+#pragma clang fp contract(off)
+  const int p1 = c + 1, p2 = bug ? c + 1 : c + 2, p3 = c + 3;
+  return ccx2 * (-split_m(u) * (10.f * w[c - 1] * (T[c] - T[c - 1])
+                                + 4.f * w[c - 2] * (T[c - 1] - T[c - 2])
+                                + w[c - 3] * (T[c - 2] - T[c - 3]))
+                 + split_p(u) * (10.f * w[p1] * (T[c] - T[p1])
+                                 + 4.f * w[p2] * (T[p1] - T[p2])
+                                 + w[p3] * (T[p2] - T[p3])))
+         / 20.f;
+}
 __device__ __forceinline__ void adv_lon_sub_strict(const float T[12], const float w[12], const float u[4],
                                                    float ccx2, bool last_quad, float d[4]) {
-#pragma clang fp contract(off)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = 4 + i;
-    const int p1 = c + 1;
-    // :881  jp2 = xdim-1 (1-based) for j = xdim-2: the "+2" neighbour aliases the "+1" one
-    const int p2 = (last_quad && i == 1) ? c + 1 : c + 2;
-    const int p3 = c + 3;
-    d[i] = ccx2 * (-split_m(u[i]) * (10.f * w[c - 1] * (T[c] - T[c - 1])
-                                     + 4.f * w[c - 2] * (T[c - 1] - T[c - 2])
-                                     + w[c - 3] * (T[c - 2] - T[c - 3]))
-                   + split_p(u[i]) * (10.f * w[p1] * (T[c] - T[p1])
-                                      + 4.f * w[p2] * (T[p1] - T[p2])
-                                      + w[p3] * (T[p2] - T[p3])))
-           / 20.f;
-  }
+  for (int i = 0; i < 4; ++i) d[i] = adv_lon_sub_point_strict(T, w, u[i], ccx2, 4 + i, last_quad && i == 1);
 }
 
 // clamp + accumulate of the sub-cycle loops (:715-716, :907-908)

@@ -1,43 +1,51 @@
 // greb_member.hip -- the fused GREB member engine for MI355X (gfx950, wave64), 96x48 grid.
 //
-// One 512-thread workgroup (8 waves, 2 per SIMD) integrates one ensemble member for a whole launch
-// (one model year): point physics, 2 x 24 circulation sub-steps, Euler update, sea ice,
-// monthly/annual accumulation (src/greb.f90:239-364, 528-553) without leaving the CU.
+// One 512-thread workgroup integrates one ensemble member for a whole launch (one model year):
+// point physics, 2 x 24 circulation sub-steps, Euler update, sea ice, monthly/annual accumulation
+// (src/greb.f90:239-364, 528-553) without leaving the CU.
 //
 // Residency
-//   LDS (150 KB)  X[2 buffers][Tair,q][48][96]  the two transported tracers, double-buffered
-//                 W[wz_air,wz_vapor][48][96]    the stencil weights (static for the run)
-//                 WX, WY [48][96]               this step's winds, scaled by the row's advection
-//                                               constants (FAST) or raw (STRICT and polar rows)
-//                 scratch                       Jacobi row buffers of the polar rows
+//   LDS (150 KB)  X[2 buffers][48][96][{Tair,q}]  the two transported tracers, INTERLEAVED and
+//                                                 double-buffered
+//                 W[48][96][{wz_air,wz_vapor}]    the stencil weights (static for the run)
+//                 WX, WY [48][96]                 this step's winds, scaled by the row's advection
+//                                                 constants (FAST) or raw (STRICT and polar rows)
+//                 row constants, Jacobi row buffers of the polar rows
 //   HBM/L2        Tsurf, Tocean, cap_surf, accumulators, forcing: touched once per model step
-//   Registers hold nothing across sub-steps but a handful of per-row constants, so the stencil
-//   code has the whole VGPR budget and never spills (v1 spilled and ran 10x slower).
+//   Registers hold nothing across sub-steps.
 //
-// Wave roles (class-uniform, so no wave executes both stencil families)
-//   waves 0-2  "sub"  tiles 4 lon x 3 lat over rows 1-9 and 38-46  (sub-cycled formulas, one sweep)
-//   waves 3-5  "full" tiles 4 lon x 4 lat over rows 10-37          (full-row formulas)
-//   waves 6-7  chain  the polar rows 0 / 47 (8 dependent Jacobi sweeps per diffusion call,
-//              src/greb.f90:656-717), both tracers side by side in one wave (lanes 0-23 / 32-55)
-// Every sub-step a bulk thread slides a 5-row window down its tile for each tracer, reading T and
-// w as dwordx4 from LDS, computes X_new = (X + dX_diffuse) + dX_advec and writes the other
-// buffer; one s_barrier per sub-step.
+// The tracer interleave makes every FAST arithmetic instruction a packed v_pk_*_f32 on an aligned
+// (Tair,q) register pair (greb_pair.h): both tracers share the winds, the sign split, the address
+// arithmetic and the row constants.
+//
+// Work distribution per sub-step (measured on MI355X: the loop is bound by VALU issue, ~1 ns per
+// wave-instruction per SIMD under load, so the lever is equal work per SIMD and full lanes):
+//   a TASK is one pair-quad of one row: 4 longitudes x (Tair,q).  The 46 non-polar rows give 432
+//   "sub" tasks (rows 1-9, 38-46: sub-cycled formulas, one sweep) and 672 "full" tasks (rows 10-37).
+//   A PASS is 64 consecutive tasks of one class, one per lane: 7 sub + 11 full passes, dealt
+//   statically to waves 0-5, three each, so no wave ever executes both stencil families.
+//   waves 6-7: the polar rows 0 / 47 (8 dependent Jacobi sweeps per diffusion call,
+//   src/greb.f90:656-717): 48 lanes x 2 longitudes x (Tair,q), neighbours through an LDS row buffer.
+// One s_barrier per sub-step.
 #include <cstdlib>
 
 #include "greb_kernels.h"
+#include "greb_pair.h"
 #include "greb_stencil.h"
 
 namespace greb {
 
 constexpr int NX = 96, NY = 48, NQ = 24, NP = 4608;
 constexpr int kThreads = 512;
+constexpr int RS = 2 * NX; // floats per interleaved row
 // LDS map, in floats
-constexpr int kOffX = 0;            // [2][2][NP]
-constexpr int kOffW = 4 * NP;       // [2][NP]
+constexpr int kOffX = 0;            // [2][NP][2]
+constexpr int kOffW = 4 * NP;       // [NP][2]
 constexpr int kOffWX = 6 * NP;      // [NP]  cu*u   (raw u in rows 0, 47 and in STRICT)
 constexpr int kOffWY = 7 * NP;      // [NP]  ccy/3*v (raw v ...)
-constexpr int kOffScr = 8 * NP;     // [2 poles][2 tracers][4][NX]
-constexpr int kLdsFloats = kOffScr + 16 * NX;
+constexpr int kOffScr = 8 * NP;     // [2 poles][2][RS]
+constexpr int kOffRowK = kOffScr + 4 * RS; // [NY][kRowKWords]
+constexpr int kLdsFloats = kOffRowK + NY * kRowKWords;
 constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
 
 // rows 0-9 / 38-47 sub-cycled, only rows 0 and 47 iterate (default kappa +-25 %)
@@ -52,119 +60,281 @@ bool member_layout_supported(const RowTables& t, int nx, int ny) {
   return true;
 }
 
-// FAST fused sub-step of one quad with pre-multiplied winds (see greb_device.h)
-template <bool SUB>
-__device__ __forceinline__ f4 substep_pm(const QuadIn& in, const f4& um, const f4& up, const f4& vm, const f4& vp,
-                                         float cs_dif, float ccy_dif, bool last_quad) {
-  Flux f;
-  make_flux(in.T, in.w, f);
-  float ddx[4], dax[4], ddy[4], day[4];
-  dif_lon_fast(f, cs_dif, ddx);
-  if (SUB) {
-    float T1h[4] = {in.T[4], in.T[5], in.T[6], in.T[7]};
-    float T2h[4] = {in.T[4], in.T[5], in.T[6], in.T[7]};
-    clamp_add_fast(T1h, ddx);                                   // :715-716
-    adv_lon_sub_pm(f, in.T, in.w, um.v, up.v, last_quad, dax);
-    clamp_add_fast(T2h, dax);                                   // :907-908
+// split a pair-quad into the two tracers' scalar quads (STRICT path)
+__device__ __forceinline__ f4 comp(const q8& q, int tr) {
+  return tr == 0 ? f4{{q.v[0].x, q.v[1].x, q.v[2].x, q.v[3].x}} : f4{{q.v[0].y, q.v[1].y, q.v[2].y, q.v[3].y}};
+}
+// interleave two fields' quads into one pair-quad
+__device__ __forceinline__ q8 zip(const f4& a, const f4& b) {
+  q8 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ddx[i] = T1h[i] - in.T[4 + i]; dax[i] = T2h[i] - in.T[4 + i]; } // :718, :910
-  } else {
-    adv_lon_full_pm(f, in.T, in.w, um.v, up.v, dax);
-  }
-  lat_pm(in.T0, in.Tm2, in.Tm1, in.Tp1, in.Tp2, in.wm2, in.wm1, in.wp1, in.wp2, vm.v, vp.v, ccy_dif, ddy, day);
-  f4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float dd = in.w0.v[i] * (ddx[i] + ddy[i]); // :721
-    const float da = dax[i] + day[i];                // :913
-    r.v[i] = (in.T[4 + i] + dd) + da;                // :549
-  }
+  for (int i = 0; i < 4; ++i) r.v[i] = v2{a.v[i], b.v[i]};
   return r;
 }
 
-// per-row constants a bulk thread keeps in registers
-struct TileK {
-  RowK rk[4];
-  float csd[4];      // dif_cc/20
-  float fm[4], fp[4]; // 3 where the latitudinal advection term is not divided by 3 (:766-769,:784-787)
-};
-
-// one circulation sub-step of a bulk tile: both tracers, rows k0..k0+H-1
-template <bool STRICT, int H>
-__device__ __forceinline__ void tile_substep(lfloat* lds, int cur, int k0, int tx, const TileK& tk) {
-  constexpr bool SUB = (H == 3);
-  const int txm = tx == 0 ? NQ - 1 : tx - 1, txp = tx == NQ - 1 ? 0 : tx + 1;
-  const int om = 4 * txm, oc = 4 * tx, op = 4 * txp;
+// ---------------------------------------------------------------------------------------------
+// one bulk task: pair-quad (k, q) -> X_new = (X + dX_diffuse) + dX_advec, both tracers
+// ---------------------------------------------------------------------------------------------
+template <bool STRICT, bool SUB>
+__device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q) {
+  const int qm = q == 0 ? NQ - 1 : q - 1, qp = q == NQ - 1 ? 0 : q + 1;
+  const lfloat* Xc = lds + kOffX + cur * 2 * NP;
+  const lfloat* Wc = lds + kOffW;
+  const lfloat* xr = Xc + k * RS;
+  const lfloat* wr = Wc + k * RS;
+  // rows beyond the grid do not occur for bulk rows 1..46 except k-2 = -1 / k+2 = 48: clamp the row,
+  // zero the weight
+  const int km2 = k >= 2 ? k - 2 : k, kp2 = k <= NY - 3 ? k + 2 : k;
+  const q8 LT = ld8(xr, qm), CT = ld8(xr, q), RT = ld8(xr, qp);
+  const q8 Tm1 = ld8(xr - RS, q), Tp1 = ld8(xr + RS, q);
+  const q8 Tm2 = ld8(Xc + km2 * RS, q), Tp2 = ld8(Xc + kp2 * RS, q);
+  const q8 LW = ld8(wr, qm), CW = ld8(wr, q), RW = ld8(wr, qp);
+  const q8 Wm1 = ld8(wr - RS, q), Wp1 = ld8(wr + RS, q);
+  const q8 Wm2 = k >= 2 ? ld8(Wc + km2 * RS, q) : zero8();
+  const q8 Wp2 = k <= NY - 3 ? ld8(Wc + kp2 * RS, q) : zero8();
+  const f4 xq = ld4(lds + kOffWX + k * NX + 4 * q), yq = ld4(lds + kOffWY + k * NX + 4 * q);
+  const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
+  q8 xn;
+  if (STRICT) {
 #pragma unroll
-  for (int tr = 0; tr < 2; ++tr) {
-    const lfloat* Xc = lds + kOffX + (cur * 2 + tr) * NP;
-    const lfloat* Wc = lds + kOffW + tr * NP;
-    lfloat* Xn = lds + kOffX + ((cur ^ 1) * 2 + tr) * NP;
-    // sliding window over latitude: 5 centre quads of T and w are live at a time
-    f4 CT[H + 4], CW[H + 4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 - 2 + i;
-      const int kc = k < 0 ? 0 : k;
-      CT[i] = ld4(Xc + kc * NX + oc);
-      CW[i] = k < 0 ? zero4() : ld4(Wc + kc * NX + oc); // rows outside the grid carry zero weight
-    }
-#pragma unroll
-    for (int r = 0; r < H; ++r) {
-      const int k = k0 + r;
-      {
-        const int kk = k + 2, kc = kk > NY - 1 ? NY - 1 : kk;
-        CT[r + 4] = ld4(Xc + kc * NX + oc);
-        CW[r + 4] = kk > NY - 1 ? zero4() : ld4(Wc + kc * NX + oc);
-      }
-      const f4 LT = ld4(Xc + k * NX + om), RT = ld4(Xc + k * NX + op);
-      const f4 LW = ld4(Wc + k * NX + om), RW = ld4(Wc + k * NX + op);
-      const f4 xq = ld4(lds + kOffWX + k * NX + oc), yq = ld4(lds + kOffWY + k * NX + oc);
+    for (int tr = 0; tr < 2; ++tr) {
       QuadIn in;
+      const f4 lt = comp(LT, tr), ct = comp(CT, tr), rt = comp(RT, tr);
+      const f4 lw = comp(LW, tr), cw = comp(CW, tr), rw = comp(RW, tr);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        in.T[j] = LT.v[j]; in.T[4 + j] = CT[r + 2].v[j]; in.T[8 + j] = RT.v[j];
-        in.w[j] = LW.v[j]; in.w[4 + j] = CW[r + 2].v[j]; in.w[8 + j] = RW.v[j];
+        in.T[j] = lt.v[j]; in.T[4 + j] = ct.v[j]; in.T[8 + j] = rt.v[j];
+        in.w[j] = lw.v[j]; in.w[4 + j] = cw.v[j]; in.w[8 + j] = rw.v[j];
       }
-      in.T0 = CT[r + 2]; in.w0 = CW[r + 2];
-      in.Tm2 = CT[r]; in.Tm1 = CT[r + 1]; in.Tp1 = CT[r + 3]; in.Tp2 = CT[r + 4];
-      in.wm2 = CW[r]; in.wm1 = CW[r + 1]; in.wp1 = CW[r + 3]; in.wp2 = CW[r + 4];
-      f4 xn;
-      if (STRICT) {
-        float dd[4], da[4];
-        dif_quad<true>(in, tk.rk[r], k, NY, dd);
-        adv_quad<true>(in, xq.v, yq.v, tk.rk[r], k, NY, tx == NQ - 1, da); // raw winds
-        {
+      in.T0 = ct; in.w0 = cw;
+      in.Tm2 = comp(Tm2, tr); in.Tm1 = comp(Tm1, tr); in.Tp1 = comp(Tp1, tr); in.Tp2 = comp(Tp2, tr);
+      in.wm2 = comp(Wm2, tr); in.wm1 = comp(Wm1, tr); in.wp1 = comp(Wp1, tr); in.wp2 = comp(Wp2, tr);
+      float dd[4], da[4];
+      dif_quad<true>(in, rk, k, NY, dd);
+      adv_quad<true>(in, xq.v, yq.v, rk, k, NY, q == NQ - 1, da); // raw winds
+      {
 #pragma clang fp contract(off)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) xn.v[i] = in.T[4 + i] + dd[i] + da[i]; // :549
-        }
-      } else {
-        f4 um, up, vm, vp;
-#pragma unroll
         for (int i = 0; i < 4; ++i) {
-          um.v[i] = fmaxf(xq.v[i], 0.f); up.v[i] = fminf(xq.v[i], 0.f);
-          vm.v[i] = tk.fm[r] * fmaxf(yq.v[i], 0.f); vp.v[i] = tk.fp[r] * fminf(yq.v[i], 0.f);
+          const float x = in.T[4 + i] + dd[i] + da[i]; // :549
+          if (tr == 0) xn.v[i].x = x; else xn.v[i].y = x;
         }
-        xn = substep_pm<SUB>(in, um, up, vm, vp, tk.csd[r], tk.rk[r].dif_ccy, tx == NQ - 1);
       }
-      st4(Xn + k * NX + oc, xn);
-      __builtin_amdgcn_sched_barrier(0); // do not hoist the next row's loads over this row's arithmetic
+    }
+  } else {
+    v2 T[12], w[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      T[j] = LT.v[j]; T[4 + j] = CT.v[j]; T[8 + j] = RT.v[j];
+      w[j] = LW.v[j]; w[4 + j] = CW.v[j]; w[8 + j] = RW.v[j];
+    }
+    // the latitudinal advection term is not divided by 3 at k = 1 (v>=0 part) and k = ny-2 (v<0 part)
+    const float fm = k == 1 ? 3.f : 1.f, fp = k == NY - 2 ? 3.f : 1.f; // :766-769, :784-787
+    float um[4], up[4], vm[4], vp[4]; // the sign split is shared by the two tracers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      um[i] = fmaxf(xq.v[i], 0.f); up[i] = fminf(xq.v[i], 0.f);
+      vm[i] = fm * fmaxf(yq.v[i], 0.f); vp[i] = fp * fminf(yq.v[i], 0.f);
+    }
+    xn = substep_pair<SUB>(T, w, Tm2, Tm1, Tp1, Tp2, Wm2, Wm1, Wp1, Wp2, um, up, vm, vp, rk.dif_cc * 0.05f,
+                           rk.dif_ccy, q == NQ - 1);
+  }
+  st8(lds + kOffX + (cur ^ 1) * 2 * NP + k * RS, q, xn);
+}
+
+// task index -> row
+__device__ __forceinline__ int sub_row(int r) { return r < 9 ? 1 + r : 38 + (r - 9); } // r = 0..17
+constexpr int kSubTasks = 18 * NQ, kFullTasks = 28 * NQ;
+
+// waves 0-5: three passes each.  Pass ids 0-6 = sub passes, 7-17 = full passes; costs are balanced
+// (a sub pass costs ~1.15 full passes).  The ids are arithmetic in the wave number so they live in
+// SGPRs: a __constant__ table costs a scalar-cache load per pass inside the sub-step loop.
+__device__ __forceinline__ int pass_of(int wave, int i) {
+  // wave: 0        1        2        3          4           5
+  //       0,1,7    2,3,8    4,5,9    6,10,11    12,13,14    15,16,17
+  if (wave < 3) return i < 2 ? 2 * wave + i : 7 + wave;
+  if (wave == 3) return i == 0 ? 6 : 9 + i;
+  return 12 + 3 * (wave - 4) + i;
+}
+
+template <bool STRICT>
+__device__ __forceinline__ void bulk_substep(lfloat* lds, int cur, int wave, int lane, int dbg) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int pass = __builtin_amdgcn_readfirstlane(pass_of(wave, i));
+    if (pass < 7) {
+      const int t = pass * 64 + lane;
+      if (t < kSubTasks && !(dbg & 1)) row_task<STRICT, true>(lds, cur, sub_row(t / NQ), t % NQ);
+    } else {
+      const int t = (pass - 7) * 64 + lane;
+      if (t < kFullTasks && !(dbg & 2)) row_task<STRICT, false>(lds, cur, 10 + t / NQ, t % NQ);
     }
   }
 }
 
-// the polar-row wave: row k (0 or 47) of both tracers, lanes 0-23 -> Tair, 32-55 -> q
+// ---------------------------------------------------------------------------------------------
+// polar rows: one wave per pole, 48 lanes x 2 longitudes x (Tair,q)
+// ---------------------------------------------------------------------------------------------
+// float offset, inside a [half][quad][4] row, of the longitude pair (2l, 2l+1)
+__device__ __forceinline__ int pair_off(int l) { return (l & 1) * kHalfRow + (l >> 1) * 4; }
+__device__ __forceinline__ void load_win10(const lfloat* row, int l, v2 t[10]) {
+  // lanes l-2 .. l+2 (mod 48) -> longitudes 2l-4 .. 2l+5
+  const int lm2 = l >= 2 ? l - 2 : l + 46, lm1 = l >= 1 ? l - 1 : 47, lp1 = l <= 46 ? l + 1 : 0, lp2 = l <= 45 ? l + 2 : l - 46;
+  const int idx[5] = {lm2, lm1, l, lp1, lp2};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const vfloat4 a = *(const __attribute__((address_space(3))) vfloat4*)(row + pair_off(idx[i]));
+    t[2 * i] = v2{a.x, a.y}; t[2 * i + 1] = v2{a.z, a.w};
+  }
+}
+__device__ __forceinline__ void st_pair2(lfloat* p, v2 a, v2 b) {
+  vfloat4 x; x.x = a.x; x.y = a.y; x.z = b.x; x.w = b.y;
+  *(__attribute__((address_space(3))) vfloat4*)p = x;
+}
+
 template <bool STRICT>
-__device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, const RowK& rk) {
-  const int lane = threadIdx.x & 63;
-  const int tr = lane >> 5, ql = lane & 31; // ql >= 24: idle lanes
+__device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole) {
+  const int l = threadIdx.x & 63;
+  if (l >= 48) return; // idle lanes (no workgroup barrier inside this function)
   const int k = pole ? NY - 1 : 0;
-  const Rows X{lds + kOffX + (cur * 2 + tr) * NP, 0, NX};
-  const Rows W{lds + kOffW + tr * NP, 0, NX};
-  const Rows U{lds + kOffWX, 0, NX}, V{lds + kOffWY, 0, NX}; // raw winds in the polar rows
-  chain_row<STRICT>(X, W, U, V, rk, k, NQ, NY, ql, kChainFused, lds + kOffScr + (pole * 2 + tr) * 4 * NX,
-                    lds + kOffX + ((cur ^ 1) * 2 + tr) * NP + k * NX);
+  const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
+  const lfloat* Xc = lds + kOffX + cur * 2 * NP;
+  const lfloat* Wc = lds + kOffW;
+  lfloat* bufA = lds + kOffScr + pole * 2 * RS;
+  lfloat* bufB = bufA + RS;
+  v2 T0w[10], w[10];
+  load_win10(Xc + k * RS, l, T0w);
+  load_win10(Wc + k * RS, l, w);
+  const float u0 = lds[kOffWX + k * NX + 2 * l], u1 = lds[kOffWX + k * NX + 2 * l + 1]; // raw winds
+  const float v0 = lds[kOffWY + k * NX + 2 * l], v1 = lds[kOffWY + k * NX + 2 * l + 1];
+  const int k1 = pole ? k - 1 : k + 1, k2 = pole ? k - 2 : k + 2; // towards the interior
+  v2 T1[2], T2[2], W1[2], W2[2];
+  {
+    const vfloat4 a = *(const __attribute__((address_space(3))) vfloat4*)(Xc + k1 * RS + pair_off(l));
+    const vfloat4 b = *(const __attribute__((address_space(3))) vfloat4*)(Xc + k2 * RS + pair_off(l));
+    const vfloat4 c = *(const __attribute__((address_space(3))) vfloat4*)(Wc + k1 * RS + pair_off(l));
+    const vfloat4 d = *(const __attribute__((address_space(3))) vfloat4*)(Wc + k2 * RS + pair_off(l));
+    T1[0] = v2{a.x, a.y}; T1[1] = v2{a.z, a.w}; T2[0] = v2{b.x, b.y}; T2[1] = v2{b.z, b.w};
+    W1[0] = v2{c.x, c.y}; W1[1] = v2{c.z, c.w}; W2[0] = v2{d.x, d.y}; W2[1] = v2{d.z, d.w};
+  }
+  const v2 own[2] = {T0w[4], T0w[5]};
+  const bool bug_lane = (l == 46); // its 2nd point is longitude xdim-2 (1-based), :881
+  const float uu[2] = {u0, u1};
+
+  v2 Th[2][2]; // [diffusion, advection][point]
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const int time2 = which ? rk.adv_time2 : rk.dif_time2;
+    const float cc = which ? rk.adv_cc : rk.dif_cc;
+    v2 T[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) T[i] = T0w[i];
+    v2 th[2] = {own[0], own[1]};
+    lfloat* src = bufA;
+    lfloat* dst = bufB;
+    for (int tt = 0; tt < time2; ++tt) {
+      if (tt > 0) load_win10(src, l, T);
+      v2 d[2];
+      if (STRICT) {
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr) {
+          float Ts[10], ws[10];
+#pragma unroll
+          for (int i = 0; i < 10; ++i) { Ts[i] = tr ? T[i].y : T[i].x; ws[i] = tr ? w[i].y : w[i].x; }
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+#pragma clang fp contract(off)
+            const int c = 4 + pt;
+            float dd;
+            if (which) dd = adv_lon_sub_point_strict(Ts, ws, uu[pt], cc, c, bug_lane && pt == 1);
+            else dd = cc * dif_S_strict(Ts, ws, c) / 20.f;
+            if (dd <= -Ts[c]) dd = -0.9f * Ts[c]; // :715 / :907
+            const float tn = Ts[c] + dd;
+            if (tr) th[pt].y = tn; else th[pt].x = tn;
+          }
+        }
+      } else {
+        v2 e[8], Pp[8], Pm[8];
+#pragma unroll
+        for (int m = 1; m <= 7; ++m) {
+          e[m] = T[m + 1] - T[m];
+          if (m >= 4) Pp[m] = w[m + 1] * e[m];
+          if (m <= 4) Pm[m] = w[m] * e[m];
+        }
+        const float cs = cc * 0.05f;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const int c = 4 + pt;
+          if (which) {
+            const float um = cs * fmaxf(uu[pt], 0.f), up = cs * fminf(uu[pt], 0.f);
+            const v2 am = 10.f * Pm[c - 1] + (4.f * Pm[c - 2] + Pm[c - 3]);
+            v2 ap = 10.f * Pp[c] + (4.f * Pp[c + 1] + Pp[c + 2]);
+            if (pt == 1) {
+              const v2 bug = 10.f * Pp[c] - w[c + 3] * (T[c + 1] - T[c + 3]);
+              ap = bug_lane ? bug : ap;
+            }
+            d[pt] = -up * ap - um * am;
+          } else {
+            const v2 a = Pp[c] - Pm[c - 1], b = Pp[c + 1] - Pm[c - 2], g = Pp[c + 2] - Pm[c - 3];
+            d[pt] = cs * (6.f * a + (3.f * b + g));
+          }
+          v2 dd = d[pt];
+          dd.x = (dd.x <= -T[c].x) ? -0.9f * T[c].x : dd.x;
+          dd.y = (dd.y <= -T[c].y) ? -0.9f * T[c].y : dd.y;
+          th[pt] = T[c] + dd;
+        }
+      }
+      if (tt + 1 < time2) { // publish for the neighbours' next sweep
+        st_pair2(dst + pair_off(l), th[0], th[1]);
+        wave_lds_sync();
+        lfloat* t = src; src = dst; dst = t;
+      }
+    }
+    Th[which][0] = th[0]; Th[which][1] = th[1];
+    wave_lds_sync(); // the advection chain reuses the row buffers
+  }
+
+  // ---- latitudinal terms + update (:585-590, :756-795, :721, :913, :549)
+  v2 xn[2];
+  const float vv[2] = {v0, v1};
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    if (STRICT) {
+#pragma unroll
+      for (int tr = 0; tr < 2; ++tr) {
+#pragma clang fp contract(off)
+        const float t0 = tr ? own[pt].y : own[pt].x, w0 = tr ? w[4 + pt].y : w[4 + pt].x;
+        const float a1 = tr ? T1[pt].y : T1[pt].x, a2 = tr ? T2[pt].y : T2[pt].x;
+        const float b1 = tr ? W1[pt].y : W1[pt].x, b2 = tr ? W2[pt].y : W2[pt].x;
+        const float vm = split_m(vv[pt]), vp = split_p(vv[pt]);
+        float dTy, aTy;
+        if (pole == 0) {
+          dTy = rk.dif_ccy * b1 * (-t0 + a1);                                        // :589
+          aTy = rk.adv_ccy * (vp * (b1 * (t0 - a1) + b2 * (t0 - a2))) / 3.f;         // :759-761
+        } else {
+          dTy = rk.dif_ccy * b1 * (a1 - t0);                                         // :590
+          aTy = rk.adv_ccy * (-vm * (b1 * (t0 - a1) + b2 * (t0 - a2))) / 3.f;        // :792-794
+        }
+        const float th0 = tr ? Th[0][pt].y : Th[0][pt].x, th1 = tr ? Th[1][pt].y : Th[1][pt].x;
+        const float dd = w0 * ((th0 - t0) + dTy); // :718, :721
+        const float da = (th1 - t0) + aTy;        // :910, :913
+        const float x = t0 + dd + da;             // :549
+        if (tr) xn[pt].y = x; else xn[pt].x = x;
+      }
+    } else {
+      const float third = rk.adv_ccy * (1.f / 3.f);
+      // pole 0: only the v<0 part couples (rows 1,2); pole 1: only the v>=0 part (rows 46,45)
+      const float cv = pole == 0 ? third * fminf(vv[pt], 0.f) : -third * fmaxf(vv[pt], 0.f);
+      const v2 g1 = W1[pt] * (T1[pt] - own[pt]);
+      const v2 d2 = W2[pt] * (own[pt] - T2[pt]);
+      const v2 ddy = rk.dif_ccy * g1;
+      const v2 day = cv * (d2 - g1);
+      const v2 dd = w[4 + pt] * ((Th[0][pt] - own[pt]) + ddy);
+      const v2 da = (Th[1][pt] - own[pt]) + day;
+      xn[pt] = (own[pt] + dd) + da;
+    }
+  }
+  st_pair2(lds + kOffX + (cur ^ 1) * 2 * NP + k * RS + pair_off(l), xn[0], xn[1]);
 }
 
 // stage this step's winds (src/greb.f90:203-216, 732): raw for STRICT and for the polar rows,
@@ -189,57 +359,21 @@ __device__ __forceinline__ void stage_winds(lfloat* lds, const float* __restrict
 __device__ __constant__ int kMonthEnd[12] = {31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334, 365};
 __device__ __constant__ int kMonthDays[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31}; // :42
 
-struct Role {
-  int kind; // 0 sub tile, 1 full tile, 2 chain, 3 idle lane
-  int k0, tx, pole;
-};
-__device__ __forceinline__ Role my_role() {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  Role r{3, 1, 0, 0};
-  if (wave < 3) {
-    if (lane < 48) {
-      const int t = wave * 48 + lane, tt = t % 72;
-      r.kind = 0; r.k0 = (t >= 72 ? 38 : 1) + 3 * (tt / NQ); r.tx = tt % NQ;
-    }
-  } else if (wave < 6) {
-    if (lane < 56) {
-      const int t = (wave - 3) * 56 + lane;
-      r.kind = 1; r.k0 = 10 + 4 * (t / NQ); r.tx = t % NQ;
-    }
-  } else {
-    r.kind = 2; r.pole = wave - 6;
-  }
-  return r;
-}
-
 // the circulation loop shared by the member kernel and its test mirror
 template <bool STRICT>
 struct Circ {
-  Role role;
-  TileK tk;
-
   __device__ __forceinline__ void init(lfloat* lds, const float* wz_air, const float* wz_vapor,
                                        const RowTables* __restrict__ tab) {
-    role = my_role();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = role.kind == 2 ? (role.pole ? NY - 1 : 0) : min(role.k0 + r, NY - 1);
-      tk.rk[r] = row_consts(*tab, k);
-      tk.csd[r] = tk.rk[r].dif_cc * 0.05f;
-      tk.fm[r] = k == 1 ? 3.f : 1.f;
-      tk.fp[r] = k == NY - 2 ? 3.f : 1.f;
-    }
-    for (int i = threadIdx.x; i < NP / 4; i += kThreads) {
-      st4(lds + kOffW + 4 * i, ld4(wz_air + 4 * i));
-      st4(lds + kOffW + NP + 4 * i, ld4(wz_vapor + 4 * i));
-    }
+    stage_row_consts(lds + kOffRowK, *tab, NY);
+    for (int i = threadIdx.x; i < NP / 4; i += kThreads)
+      st8(lds + kOffW + (i / NQ) * RS, i % NQ, zip(ld4(wz_air + 4 * i), ld4(wz_vapor + 4 * i)));
   }
 
   // dbg: timing experiments only (tools/microbench_circ.py): bit0/1/2 skip sub / full / chain work
   __device__ __forceinline__ void substep(lfloat* lds, int cur, int dbg = 0) {
-    if (role.kind == 0) { if (!(dbg & 1)) tile_substep<STRICT, 3>(lds, cur, role.k0, role.tx, tk); }
-    else if (role.kind == 1) { if (!(dbg & 2)) tile_substep<STRICT, 4>(lds, cur, role.k0, role.tx, tk); }
-    else if (role.kind == 2) { if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, role.pole, tk.rk[0]); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 6) bulk_substep<STRICT>(lds, cur, wave, lane, dbg);
+    else if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, wave - 6);
   }
 };
 
@@ -262,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void circulation_g96_kernel(const float* 
   c.init(lds, wz + fo, wz + fo, tab);
   for (int i = threadIdx.x; i < NP / 4; i += kThreads) {
     const f4 x = ld4(Xin + fo + 4 * i);
-    st4(lds + kOffX + 4 * i, x); st4(lds + kOffX + NP + 4 * i, x);
+    st8(lds + kOffX + (i / NQ) * RS, i % NQ, zip(x, x));
   }
   stage_winds<STRICT>(lds, ug + fo, vg + fo, tab);
   __syncthreads();
@@ -274,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void circulation_g96_kernel(const float* 
     cur ^= 1;
   }
   for (int i = threadIdx.x; i < NP / 4; i += kThreads) {
-    const f4 a = ld4(lds + kOffX + cur * 2 * NP + 4 * i), b = ld4(Xin + fo + 4 * i);
+    const f4 a = comp(ld8(lds + kOffX + cur * 2 * NP + (i / NQ) * RS, i % NQ), 0), b = ld4(Xin + fo + 4 * i);
     st4(dX + fo + 4 * i, f4{{a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2], a.v[3] - b.v[3]}}); // :551
   }
 }
@@ -305,10 +439,8 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
 
   Circ<STRICT> circ;
   circ.init(lds, a.wz_air, a.wz_vapor, tab);
-  for (int i = tid; i < NP / 4; i += kThreads) {
-    st4(lds + kOffX + 4 * i, ld4(state + NP + 4 * i));          // Tair
-    st4(lds + kOffX + NP + 4 * i, ld4(state + 3 * NP + 4 * i)); // q
-  }
+  for (int i = tid; i < NP / 4; i += kThreads)
+    st8(lds + kOffX + (i / NQ) * RS, i % NQ, zip(ld4(state + NP + 4 * i), ld4(state + 3 * NP + 4 * i))); // (Tair, q)
   int cur = 0;
   __syncthreads();
 
@@ -359,7 +491,8 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
       f4 acc0, acc1, acc2, acc3, acc4;
       const f4 acc5 = ld4(acc + 5 * NP + p0);
       if (!FLUX) { acc0 = ld4(acc + p0); acc1 = ld4(acc + NP + p0); acc2 = ld4(acc + 2 * NP + p0); acc3 = ld4(acc + 3 * NP + p0); acc4 = ld4(acc + 4 * NP + p0); }
-      const f4 xTa = ld4(Xf + p0), xq = ld4(Xf + NP + p0);
+      const q8 xpair = ld8(Xf + (qd / NQ) * RS, qd % NQ);
+      const f4 xTa = comp(xpair, 0), xq = comp(xpair, 1);
       f4 oTs, oTa, oTo, oq, ocap, oTF, oqF, oToF, oalb, otsmn;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -407,7 +540,7 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
       }
       st4(state + p0, oTs); st4(state + NP + p0, oTa); st4(state + 2 * NP + p0, oTo); st4(state + 3 * NP + p0, oq);
       st4(state + 4 * NP + p0, ocap);
-      st4(Xf + p0, oTa); st4(Xf + NP + p0, oq);
+      st8(Xf + (qd / NQ) * RS, qd % NQ, zip(oTa, oq));
       if (FLUX) {
         st4(corr + off + p0, oTF); st4(corr + (size_t)kNT * NP + off + p0, oqF); st4(corr + (size_t)2 * kNT * NP + off + p0, oToF);
       } else {
