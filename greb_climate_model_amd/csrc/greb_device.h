@@ -290,6 +290,16 @@ __device__ __forceinline__ void lat_pm(const f4& T0, const f4& Tm2, const f4& Tm
 // STRICT keeps the reference's operation order (x**4 = ((x*x)*x)*x as flang -O2 lowers it); the
 // only non-bit-exact parts are OCML expf/logf vs glibc (<= 1-2 ulp on fluxes).
 // ============================================================================================
+// Math policy of the point physics.  EXACT: IEEE division / OCML logf, expf, sqrtf (STRICT engine,
+// bit-exact where no transcendental is involved).  Otherwise the hardware approximations
+// v_rcp/v_log/v_exp/v_sqrt (<= 1-2 ulp): the fluxes they feed enter the state scaled by
+// dt/cap ~ 1e-3..1e-1 K, far below the 1e-4 K tolerance, and they cut the per-point instruction
+// count ~3x (the physics phase is VALU-bound: ~14 divisions, 4 transcendentals per point).
+template <bool EXACT> __device__ __forceinline__ float fdiv(float a, float b) { return EXACT ? a / b : __fdividef(a, b); }
+template <bool EXACT> __device__ __forceinline__ float flog(float x) { return EXACT ? logf(x) : __logf(x); }
+template <bool EXACT> __device__ __forceinline__ float fexp(float x) { return EXACT ? expf(x) : __expf(x); }
+template <bool EXACT> __device__ __forceinline__ float fsqrt(float x) { return EXACT ? sqrtf(x) : __builtin_amdgcn_sqrtf(x); }
+
 struct Phys { // namelist physics_par + derived capacities, broadcast to the kernel
   float sig, ct_sens, da_ice, a_no_ice, a_cloud, Tl_ice1, Tl_ice2, To_ice1, To_ice2;
   float co_turb, ce, cq_latent, cq_rain, z_air, r_qviwv, rho_air;
@@ -304,6 +314,7 @@ __device__ __forceinline__ float pow4_ref(float x) {
 }
 
 // a4 SWradiation :380-401 -> albedo, sw
+template <bool EXACT = true>
 __device__ __forceinline__ void sw_radiation(const Phys& P, float Ts, float z_topo, float glacier, float cld,
                                              float sw_solar, float& albedo, float& sw) {
 #pragma clang fp contract(off)
@@ -313,12 +324,12 @@ __device__ __forceinline__ void sw_radiation(const Phys& P, float Ts, float z_to
     if (Ts <= P.Tl_ice1) a_surf = P.a_no_ice + P.da_ice;
     if (Ts >= P.Tl_ice2) a_surf = P.a_no_ice;
     if (Ts > P.Tl_ice1 && Ts < P.Tl_ice2)
-      a_surf = P.a_no_ice + P.da_ice * (1.f - (Ts - P.Tl_ice1) / (P.Tl_ice2 - P.Tl_ice1));
+      a_surf = P.a_no_ice + P.da_ice * (1.f - fdiv<EXACT>(Ts - P.Tl_ice1, P.Tl_ice2 - P.Tl_ice1));
   } else {
     if (Ts <= P.To_ice1) a_surf = P.a_no_ice + P.da_ice;
     if (Ts >= P.To_ice2) a_surf = P.a_no_ice;
     if (Ts > P.To_ice1 && Ts < P.To_ice2)
-      a_surf = P.a_no_ice + P.da_ice * (1.f - (Ts - P.To_ice1) / (P.To_ice2 - P.To_ice1));
+      a_surf = P.a_no_ice + P.da_ice * (1.f - fdiv<EXACT>(Ts - P.To_ice1, P.To_ice2 - P.To_ice1));
   }
   if (glacier > 0.5f) a_surf = P.a_no_ice + P.da_ice;
   albedo = a_surf + a_atmos - a_surf * a_atmos;
@@ -326,16 +337,17 @@ __device__ __forceinline__ void sw_radiation(const Phys& P, float Ts, float z_to
 }
 
 // a5 LWradiation :420-432.  ez = exp(-z_topo/z_air) (== wz_air, :201), dTrad = -0.16*Tclim-5 (:176)
+template <bool EXACT = true>
 __device__ __forceinline__ void lw_radiation(const Phys& P, float Ts, float Ta, float q, float co2, float ez,
                                              float cld, float tclim, float& LWsurf, float& LWair_down,
                                              float& em) {
 #pragma clang fp contract(off)
   const float e_co2 = ez * co2;
   const float e_vapor = ez * P.r_qviwv * q;
-  float e = P.p_emi[3] * logf(P.p_emi[0] * e_co2 + P.p_emi[1] * e_vapor + P.p_emi[2]) + P.p_emi[6]
-            + P.p_emi[4] * logf(P.p_emi[0] * e_co2 + P.p_emi[2])
-            + P.p_emi[5] * logf(P.p_emi[1] * e_vapor + P.p_emi[2]);
-  e = (P.p_emi[7] - cld) / P.p_emi[8] * (e - P.p_emi[9]) + P.p_emi[9];
+  float e = P.p_emi[3] * flog<EXACT>(P.p_emi[0] * e_co2 + P.p_emi[1] * e_vapor + P.p_emi[2]) + P.p_emi[6]
+            + P.p_emi[4] * flog<EXACT>(P.p_emi[0] * e_co2 + P.p_emi[2])
+            + P.p_emi[5] * flog<EXACT>(P.p_emi[1] * e_vapor + P.p_emi[2]);
+  e = fdiv<EXACT>(P.p_emi[7] - cld, P.p_emi[8]) * (e - P.p_emi[9]) + P.p_emi[9];
   em = e;
   LWsurf = -P.sig * pow4_ref(Ts);
   const float dTrad = -0.16f * tclim - 5.f;
@@ -343,37 +355,40 @@ __device__ __forceinline__ void lw_radiation(const Phys& P, float Ts, float Ta, 
 }
 
 // a6 hydro :452-467
+template <bool EXACT = true>
 __device__ __forceinline__ void hydro(const Phys& P, float Ts, float q, float u, float v, float z_topo,
                                       float ez, float swet, float& Qlat, float& Qlat_air, float& dq_eva,
                                       float& dq_rain) {
 #pragma clang fp contract(off)
-  float abswind = sqrtf(u * u + v * v);
-  if (z_topo > 0.f) abswind = sqrtf(abswind * abswind + 2.0f * 2.0f);
-  if (z_topo < 0.f) abswind = sqrtf(abswind * abswind + 3.0f * 3.0f);
-  float qs = 3.75e-3f * expf(17.08085f * (Ts - 273.15f) / (Ts - 273.15f + 234.175f));
+  float abswind = fsqrt<EXACT>(u * u + v * v);
+  if (z_topo > 0.f) abswind = fsqrt<EXACT>(abswind * abswind + 2.0f * 2.0f);
+  if (z_topo < 0.f) abswind = fsqrt<EXACT>(abswind * abswind + 3.0f * 3.0f);
+  float qs = 3.75e-3f * fexp<EXACT>(fdiv<EXACT>(17.08085f * (Ts - 273.15f), Ts - 273.15f + 234.175f));
   qs = qs * ez;
   Qlat = (q - qs) * abswind * P.cq_latent * P.rho_air * P.ce * swet;
-  dq_eva = -Qlat / P.cq_latent / P.r_qviwv;
+  dq_eva = fdiv<EXACT>(fdiv<EXACT>(-Qlat, P.cq_latent), P.r_qviwv);
   dq_rain = P.cq_rain * q;
   Qlat_air = -dq_rain * P.cq_latent * P.r_qviwv;
 }
 
 // a7 deep_ocean :505-523
+template <bool EXACT = true>
 __device__ __forceinline__ void deep_ocean(const Phys& P, float Ts, float To, float z_topo, float mld,
                                            float mld_prev, float z_ocean, float& dT_ocean, float& dTo) {
 #pragma clang fp contract(off)
   float a = 0.f, b = 0.f;
   const float dmld = mld - mld_prev;
-  if (z_topo < 0.f && Ts >= P.To_ice2 && dmld < 0.f) a = -dmld / (z_ocean - mld) * (Ts - To);
-  if (z_topo < 0.f && Ts >= P.To_ice2 && dmld > 0.f) b = dmld / mld * (To - Ts);
+  if (z_topo < 0.f && Ts >= P.To_ice2 && dmld < 0.f) a = fdiv<EXACT>(-dmld, z_ocean - mld) * (Ts - To);
+  if (z_topo < 0.f && Ts >= P.To_ice2 && dmld > 0.f) b = fdiv<EXACT>(dmld, mld) * (To - Ts);
   a = 0.5f * a; b = 0.5f * b;
   const float Tx = P.To_ice2 > Ts ? P.To_ice2 : Ts;
-  a = a + P.dt * P.co_turb * (Tx - To) / (P.cap_ocean * (z_ocean - mld));
-  b = b + P.dt * P.co_turb * (To - Tx) / (P.cap_ocean * mld);
+  a = a + fdiv<EXACT>(P.dt * P.co_turb * (Tx - To), P.cap_ocean * (z_ocean - mld));
+  b = b + fdiv<EXACT>(P.dt * P.co_turb * (To - Tx), P.cap_ocean * mld);
   dTo = a; dT_ocean = b;
 }
 
 // a8 seaice :483-490 -> new cap_surf
+template <bool EXACT = true>
 __device__ __forceinline__ float seaice(const Phys& P, float Ts, float z_topo, float glacier, float mld,
                                         float cap_surf) {
 #pragma clang fp contract(off)
@@ -381,7 +396,7 @@ __device__ __forceinline__ float seaice(const Phys& P, float Ts, float z_topo, f
     if (Ts <= P.To_ice1) cap_surf = P.cap_land;
     if (Ts >= P.To_ice2) cap_surf = P.cap_ocean * mld;
     if (Ts > P.To_ice1 && Ts < P.To_ice2)
-      cap_surf = P.cap_land + (P.cap_ocean * mld - P.cap_land) / (P.To_ice2 - P.To_ice1) * (Ts - P.To_ice1);
+      cap_surf = P.cap_land + fdiv<EXACT>(P.cap_ocean * mld - P.cap_land, P.To_ice2 - P.To_ice1) * (Ts - P.To_ice1);
   }
   if (glacier > 0.5f) cap_surf = P.cap_land;
   return cap_surf;

@@ -502,23 +502,23 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
         const float dTa_crcl = xTa.v[e] - Ta1; // :551
         const float dq_crcl = xq.v[e] - q1;
         float albedo, sw, LWsurf, LWdown, em, Qlat, Qlat_air, dq_eva, dq_rain, dT_ocean, dTo;
-        sw_radiation(P, Ts1, zt, gl, cld, solar, albedo, sw);
-        lw_radiation(P, Ts1, Ta1, q1, co2, ez, cld, tcl, LWsurf, LWdown, em);
+        sw_radiation<STRICT>(P, Ts1, zt, gl, cld, solar, albedo, sw);
+        lw_radiation<STRICT>(P, Ts1, Ta1, q1, co2, ez, cld, tcl, LWsurf, LWdown, em);
         const float Qsens = P.ct_sens * (Ta1 - Ts1); // :295
-        hydro(P, Ts1, q1, vu.v[e], vv.v[e], zt, ez, vswet.v[e], Qlat, Qlat_air, dq_eva, dq_rain);
-        deep_ocean(P, Ts1, To1, zt, mld, vmldm.v[e], vzo.v[e], dT_ocean, dTo);
+        hydro<STRICT>(P, Ts1, q1, vu.v[e], vv.v[e], zt, ez, vswet.v[e], Qlat, Qlat_air, dq_eva, dq_rain);
+        deep_ocean<STRICT>(P, Ts1, To1, zt, mld, vmldm.v[e], vzo.v[e], dT_ocean, dTo);
         const float LWup = LWdown; // :432
         float Ts0, Ta0, To0, q0;
         if (FLUX) {
-          const float dTs = P.dt * (sw + LWsurf - LWdown + Qlat + Qsens) / cap;                    // :333
+          const float dTs = fdiv<STRICT>(P.dt * (sw + LWsurf - LWdown + Qlat + Qsens), cap);                    // :333
           Ts0 = Ts1 + dTs + dT_ocean;                                                              // :334
-          const float dTa = P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens) / P.cap_air;   // :336
+          const float dTa = fdiv<STRICT>(P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens), P.cap_air);   // :336
           Ta0 = Ta1 + dTa + dTa_crcl;                                                              // :337
           To0 = To1 + dTo;                                                                         // :339
           const float dq = P.dt * (dq_eva + dq_rain);                                              // :341
           q0 = q1 + dq + dq_crcl;                                                                  // :342
-          const float TF = (tcl - Ts0) * cap / P.dt;                                               // :344-345
-          Ts0 = Ts1 + dTs + dT_ocean + TF * P.dt / cap;                                            // :347
+          const float TF = fdiv<STRICT>((tcl - Ts0) * cap, P.dt);                                               // :344-345
+          Ts0 = Ts1 + dTs + dT_ocean + fdiv<STRICT>(TF * P.dt, cap);                                            // :347
           const float ToF = vc0.v[e] - To0;                                                        // :349
           To0 = To1 + dTo + ToF;                                                                   // :351
           const float qF = vc1.v[e] - q0;                                                          // :353
@@ -526,15 +526,15 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
           oTF.v[e] = TF; oqF.v[e] = qF; oToF.v[e] = ToF;
         } else {
           const float TF = vc0.v[e], qF = vc1.v[e], ToF = vc2.v[e];
-          Ts0 = Ts1 + dT_ocean + P.dt * (sw + LWsurf - LWdown + Qlat + Qsens + TF) / cap;          // :258
-          Ta0 = Ta1 + dTa_crcl + P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens) / P.cap_air; // :260
+          Ts0 = Ts1 + dT_ocean + fdiv<STRICT>(P.dt * (sw + LWsurf - LWdown + Qlat + Qsens + TF), cap);          // :258
+          Ta0 = Ta1 + dTa_crcl + fdiv<STRICT>(P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens), P.cap_air); // :260
           To0 = To1 + dTo + ToF;                                                                   // :262
           float dq = P.dt * (dq_eva + dq_rain) + dq_crcl + qF;                                     // :264
           if (dq <= -q1) dq = -0.9f * q1;                                                          // :265
           q0 = q1 + dq;                                                                            // :266
         }
         oTs.v[e] = Ts0; oTa.v[e] = Ta0; oTo.v[e] = To0; oq.v[e] = q0;
-        ocap.v[e] = seaice(P, Ts0, zt, gl, mld, cap);                                              // :268/:357
+        ocap.v[e] = seaice<STRICT>(P, Ts0, zt, gl, mld, cap);                                              // :268/:357
         oalb.v[e] = albedo;
         otsmn.v[e] = acc5.v[e] + Ts0;                                                              // :945
       }
