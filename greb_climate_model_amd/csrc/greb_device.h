@@ -58,6 +58,8 @@ __device__ __forceinline__ void st4(lfloat* p, const f4& a) {
   *(__attribute__((address_space(3))) vfloat4*)p = v;
 }
 
+__device__ __forceinline__ f4 zero4() { return f4{{0.f, 0.f, 0.f, 0.f}}; }
+
 // window of 12 longitudes around quad q of a row (periodic, src/greb.f90:594,602,610,...)
 template <typename P>
 __device__ __forceinline__ void load_window(P row, int q, int nq, float t[12]) {

@@ -31,6 +31,7 @@
 
 #include "greb_kernels.h"
 #include "greb_pair.h"
+#include "greb_physics_step.h"
 #include "greb_stencil.h"
 
 namespace greb {
@@ -356,9 +357,6 @@ __device__ __forceinline__ void stage_winds(lfloat* lds, const float* __restrict
   }
 }
 
-__device__ __constant__ int kMonthEnd[12] = {31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334, 365};
-__device__ __constant__ int kMonthDays[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31}; // :42
-
 // the circulation loop shared by the member kernel and its test mirror
 template <bool STRICT>
 struct Circ {
@@ -447,11 +445,9 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
 #pragma unroll 1
   for (int s = 0; s < a.nsteps; ++s) {
     const long long it = a.it0 + s;
-    const int ityr = (int)((it - 1) % kNT) + 1;                       // :252
-    const int jday = (int)(((it - 1) / 2) % 365) + 1;                 // :251
-    const size_t off = (size_t)(ityr - 1) * NP;
-    const size_t offm = (size_t)(ityr > 1 ? ityr - 2 : kNT - 1) * NP; // :507-508
-    const int yr_rel = (int)((it - 1) / kNT - (a.it0 - 1) / kNT);     // whole years since launch start
+    const StepClock ck = step_clock<FLUX>(a, it, NP);
+    const int ityr = ck.ityr, yr_rel = ck.yr_rel;
+    const size_t off = ck.off;
 
     stage_winds<STRICT>(lds, a.uclim + off, a.vclim + off, tab);
     __syncthreads();
@@ -465,9 +461,6 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     }
 
     // ---- point physics on the OLD state + Euler update (:254-268 / :328-361)
-    int mon = -1; // 0-based month whose last day this is, else -1
-    if (!FLUX && (it % 2 == 0))
-      for (int mm = 0; mm < 12; ++mm) if (jday == kMonthEnd[mm]) mon = mm; // :975-976
     const Phys P = a.phys[m];
     const float co2 = FLUX ? a.co2_flux : a.co2[(size_t)m * a.co2_stride + a.co2_year0 + yr_rel]; // :924
     lfloat* Xf = lds + kOffX + cur * 2 * NP;       // the tracers after the 24 sub-steps
@@ -477,103 +470,11 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     // a step pays ~3 dependent HBM/L2 round trips per thread instead of 9.
 #pragma unroll 1
     for (int qd = tid; qd < NP / 4; qd += kThreads) {
-      const int p0 = 4 * qd;
-      const f4 vTs = ld4(state + p0), vTa = ld4(state + NP + p0), vTo = ld4(state + 2 * NP + p0),
-               vq = ld4(state + 3 * NP + p0), vcap = ld4(state + 4 * NP + p0);
-      const f4 vzt = ld4(a.z_topo + p0), vgl = ld4(a.glacier + p0), vzo = ld4(a.z_ocean + p0), vez = ld4(a.wz_air + p0);
-      const f4 vtcl = ld4(a.tclim + off + p0), vcld = ld4(a.cldclim + off + p0), vmld = ld4(a.mldclim + off + p0),
-               vmldm = ld4(a.mldclim + offm + p0), vswet = ld4(a.swetclim + off + p0), vu = ld4(a.uclim + off + p0),
-               vv = ld4(a.vclim + off + p0);
-      const float solar = a.sw_solar[(size_t)(ityr - 1) * NY + p0 / NX]; // a quad never straddles rows
-      f4 vc0, vc1, vc2; // flux: Toclim, qclim, -- ; scenario: TF, qF, ToF
-      if (FLUX) { vc0 = ld4(a.toclim + p0); vc1 = ld4(a.qclim + off + p0); vc2 = zero4(); }
-      else { vc0 = ld4(corr + off + p0); vc1 = ld4(corr + (size_t)kNT * NP + off + p0); vc2 = ld4(corr + (size_t)2 * kNT * NP + off + p0); }
-      f4 acc0, acc1, acc2, acc3, acc4;
-      const f4 acc5 = ld4(acc + 5 * NP + p0);
-      if (!FLUX) { acc0 = ld4(acc + p0); acc1 = ld4(acc + NP + p0); acc2 = ld4(acc + 2 * NP + p0); acc3 = ld4(acc + 3 * NP + p0); acc4 = ld4(acc + 4 * NP + p0); }
       const q8 xpair = ld8(Xf + (qd / NQ) * RS, qd % NQ);
-      const f4 xTa = comp(xpair, 0), xq = comp(xpair, 1);
-      f4 oTs, oTa, oTo, oq, ocap, oTF, oqF, oToF, oalb, otsmn;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-#pragma clang fp contract(off)
-        const float Ts1 = vTs.v[e], Ta1 = vTa.v[e], To1 = vTo.v[e], q1 = vq.v[e], cap = vcap.v[e];
-        const float zt = vzt.v[e], gl = vgl.v[e], ez = vez.v[e], tcl = vtcl.v[e], cld = vcld.v[e], mld = vmld.v[e];
-        const float dTa_crcl = xTa.v[e] - Ta1; // :551
-        const float dq_crcl = xq.v[e] - q1;
-        float albedo, sw, LWsurf, LWdown, em, Qlat, Qlat_air, dq_eva, dq_rain, dT_ocean, dTo;
-        sw_radiation<STRICT>(P, Ts1, zt, gl, cld, solar, albedo, sw);
-        lw_radiation<STRICT>(P, Ts1, Ta1, q1, co2, ez, cld, tcl, LWsurf, LWdown, em);
-        const float Qsens = P.ct_sens * (Ta1 - Ts1); // :295
-        hydro<STRICT>(P, Ts1, q1, vu.v[e], vv.v[e], zt, ez, vswet.v[e], Qlat, Qlat_air, dq_eva, dq_rain);
-        deep_ocean<STRICT>(P, Ts1, To1, zt, mld, vmldm.v[e], vzo.v[e], dT_ocean, dTo);
-        const float LWup = LWdown; // :432
-        float Ts0, Ta0, To0, q0;
-        if (FLUX) {
-          const float dTs = fdiv<STRICT>(P.dt * (sw + LWsurf - LWdown + Qlat + Qsens), cap);                    // :333
-          Ts0 = Ts1 + dTs + dT_ocean;                                                              // :334
-          const float dTa = fdiv<STRICT>(P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens), P.cap_air);   // :336
-          Ta0 = Ta1 + dTa + dTa_crcl;                                                              // :337
-          To0 = To1 + dTo;                                                                         // :339
-          const float dq = P.dt * (dq_eva + dq_rain);                                              // :341
-          q0 = q1 + dq + dq_crcl;                                                                  // :342
-          const float TF = fdiv<STRICT>((tcl - Ts0) * cap, P.dt);                                               // :344-345
-          Ts0 = Ts1 + dTs + dT_ocean + fdiv<STRICT>(TF * P.dt, cap);                                            // :347
-          const float ToF = vc0.v[e] - To0;                                                        // :349
-          To0 = To1 + dTo + ToF;                                                                   // :351
-          const float qF = vc1.v[e] - q0;                                                          // :353
-          q0 = q1 + dq + dq_crcl + qF;                                                             // :355
-          oTF.v[e] = TF; oqF.v[e] = qF; oToF.v[e] = ToF;
-        } else {
-          const float TF = vc0.v[e], qF = vc1.v[e], ToF = vc2.v[e];
-          Ts0 = Ts1 + dT_ocean + fdiv<STRICT>(P.dt * (sw + LWsurf - LWdown + Qlat + Qsens + TF), cap);          // :258
-          Ta0 = Ta1 + dTa_crcl + fdiv<STRICT>(P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens), P.cap_air); // :260
-          To0 = To1 + dTo + ToF;                                                                   // :262
-          float dq = P.dt * (dq_eva + dq_rain) + dq_crcl + qF;                                     // :264
-          if (dq <= -q1) dq = -0.9f * q1;                                                          // :265
-          q0 = q1 + dq;                                                                            // :266
-        }
-        oTs.v[e] = Ts0; oTa.v[e] = Ta0; oTo.v[e] = To0; oq.v[e] = q0;
-        ocap.v[e] = seaice<STRICT>(P, Ts0, zt, gl, mld, cap);                                              // :268/:357
-        oalb.v[e] = albedo;
-        otsmn.v[e] = acc5.v[e] + Ts0;                                                              // :945
-      }
-      st4(state + p0, oTs); st4(state + NP + p0, oTa); st4(state + 2 * NP + p0, oTo); st4(state + 3 * NP + p0, oq);
-      st4(state + 4 * NP + p0, ocap);
+      f4 oTa, oq, tsm;
+      physics_quad<STRICT, FLUX>(a, P, m, qd, ck, co2, state, acc, corr, comp(xpair, 0), comp(xpair, 1), oTa, oq, tsm);
       st8(Xf + (qd / NQ) * RS, qd % NQ, zip(oTa, oq));
-      if (FLUX) {
-        st4(corr + off + p0, oTF); st4(corr + (size_t)kNT * NP + off + p0, oqF); st4(corr + (size_t)2 * kNT * NP + off + p0, oToF);
-      } else {
-#pragma clang fp contract(off)
-        f4 s0, s1, s2, s3, s4; // :974
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s0.v[e] = acc0.v[e] + oTs.v[e]; s1.v[e] = acc1.v[e] + oTa.v[e]; s2.v[e] = acc2.v[e] + oTo.v[e];
-          s3.v[e] = acc3.v[e] + oq.v[e]; s4.v[e] = acc4.v[e] + oalb.v[e];
-        }
-        if (mon >= 0) { // :975-984
-          const float ndm = (float)(kMonthDays[mon] * 2);
-          float* rec = a.monthly + (((size_t)m * a.monthly_years + (a.year_out0 + yr_rel)) * 12 + mon) * 5 * NP;
-          f4 r0, r1, r2, r3, r4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            r0.v[e] = s0.v[e] / ndm; r1.v[e] = s1.v[e] / ndm; r2.v[e] = s2.v[e] / ndm; r3.v[e] = s3.v[e] / ndm; r4.v[e] = s4.v[e] / ndm;
-          }
-          st4(rec + p0, r0); st4(rec + NP + p0, r1); st4(rec + 2 * NP + p0, r2); st4(rec + 3 * NP + p0, r3); st4(rec + 4 * NP + p0, r4);
-          s0 = s1 = s2 = s3 = s4 = zero4();
-        }
-        st4(acc + p0, s0); st4(acc + NP + p0, s1); st4(acc + 2 * NP + p0, s2); st4(acc + 3 * NP + p0, s3); st4(acc + 4 * NP + p0, s4);
-      }
-      if (ityr == kNT) { // :948-956
-#pragma clang fp contract(off)
-        f4 t;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t.v[e] = otsmn.v[e] / (float)kNT;
-        st4(red + p0, t);
-        st4(acc + 5 * NP + p0, zero4());
-      } else {
-        st4(acc + 5 * NP + p0, otsmn);
-      }
+      if (ityr == kNT) st4(red + 4 * qd, tsm);
     }
     if (ityr == kNT) {
       __syncthreads();

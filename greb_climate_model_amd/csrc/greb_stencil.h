@@ -27,7 +27,6 @@ struct QuadIn {
   f4 T0, w0, Tm2, Tm1, Tp1, Tp2, wm2, wm1, wp1, wp2;
 };
 
-__device__ __forceinline__ f4 zero4() { return f4{{0.f, 0.f, 0.f, 0.f}}; }
 
 // the constants one latitude row needs (a register-resident slice of RowTables)
 struct RowK {
