@@ -9,6 +9,7 @@ import numpy as np
 NSTEP_YR = 730
 NVAR_OUT = 5
 F_STRICT = 1
+F_MULTILAUNCH = 2
 RUN_DEVICE_OUT = 1
 
 c_float_p = C.POINTER(C.c_float)

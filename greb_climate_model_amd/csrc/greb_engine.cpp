@@ -103,6 +103,8 @@ struct greb_engine {
   int nx = 0, ny = 0, np = 0, nm = 0, device = 0;
   bool strict = false;
   bool shared_corr = true; // all members share physics -> one flux-correction set
+  bool fused = true;       // every member has the 96x48 default sub-cycling layout -> fused member kernel
+  float *Xa = nullptr, *Xb = nullptr, *red = nullptr, *W2 = nullptr; // any-grid (multi-launch) engine work arrays
   hipStream_t stream = nullptr;
   // device
   float *z_topo = nullptr, *glacier = nullptr, *sw_solar = nullptr;
@@ -161,6 +163,35 @@ int ensure(greb_engine* e, float** buf, size_t* cap, size_t n) {
   *cap = n;
   return 0;
 }
+
+// One model year (730 steps) for the first `nrun` members, `a` describing that year.
+//   fused layout : one launch of the member kernel
+//   other grids  : 24 fused band sub-steps + 1 point-physics launch per model step
+int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
+  if (e->fused) {
+    HIP_TRY(e, launch_member_kernel(a, nrun, e->strict, e->stream));
+    return 0;
+  }
+  const size_t np = (size_t)e->np;
+  HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
+  for (int s = 0; s < kNT; ++s) {
+    const long long it = a.it0 + s;
+    const int ityr = (int)((it - 1) % kNT) + 1;
+    const size_t off = (size_t)(ityr - 1) * np;
+    float *cur = e->Xa, *nxt = e->Xb;
+    for (int tt = 0; tt < a.nsub; ++tt) {
+      HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
+                                      e->ny, nrun, e->strict, e->stream));
+      float* t = cur; cur = nxt; nxt = t;
+    }
+    MemberArgs b = a;
+    b.it0 = it; b.nsteps = 1; // the step kernel derives its clock from it0; year indices are those of `a`
+    HIP_TRY(e, launch_physics_step(b, cur, e->Xa, e->red, nrun, e->strict, e->stream));
+    if (ityr == kNT && a.yearly)
+      HIP_TRY(e, launch_yearly(e->red, a.yearly, e->np, e->nx, a.ipx, a.ipy, a.yearly_years, a.yearly_year0, nrun, e->stream));
+  }
+  return 0;
+}
 } // namespace
 
 extern "C" {
@@ -211,17 +242,11 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
     return fail(nullptr, GREB_E_NOGPU, "greb_engine_create: no HIP device (the engine has no CPU path)");
-  if (!(nx == 96 && ny == 48))
-    return fail(nullptr, GREB_E_UNSUPPORTED,
-                "greb_engine_create: the fused member engine supports the 96x48 grid only in this build "
-                "(the batched diffusion/advection/circulation entry points take any grid)");
+  bool fused = true;
   for (int m = 0; m < n_members; ++m) {
     const float kap = (overrides && !std::isnan(overrides[m].kappa)) ? overrides[m].kappa : p->kappa;
     RowTables t; compute_row_tables(*p, kap, nx, ny, t);
-    if (!member_layout_supported(t, nx, ny))
-      return fail(nullptr, GREB_E_UNSUPPORTED,
-                  "greb_engine_create: these pi/kappa/dt_crcl give a sub-cycling layout other than rows 1-10/39-48 "
-                  "with two iterating polar rows; the fused engine is specialised for that layout");
+    fused = fused && member_layout_supported(t, nx, ny);
   }
   if (p->ipx < 1 || p->ipx > nx || p->ipy < 1 || p->ipy > ny)
     return fail(nullptr, GREB_E_INVALID, "greb_engine_create: ipx/ipy outside the grid");
@@ -230,6 +255,7 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
   *out = e; // returned even on failure so last_error can be read; caller destroys
   e->p = *p; e->nx = nx; e->ny = ny; e->np = nx * ny; e->nm = n_members; e->device = device;
   e->strict = (flags & GREB_F_STRICT) != 0;
+  e->fused = fused && !(flags & GREB_F_MULTILAUNCH);
   const size_t np = (size_t)e->np, n3 = np * kNT, nm = (size_t)n_members;
   HIP_TRY(e, hipSetDevice(device));
   HIP_TRY(e, hipStreamCreate(&e->stream));
@@ -320,6 +346,14 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
     }
     HIP_TRY(e, hipMemcpy(e->state + m * 5 * np, st.data(), 5 * np * sizeof(float), hipMemcpyHostToDevice));
   }
+  if (!e->fused) { // the member does not fit one CU (or has another sub-cycling layout): multi-launch engine
+    HIP_TRY(e, dev_alloc(&e->Xa, nm * 2 * np));
+    HIP_TRY(e, dev_alloc(&e->Xb, nm * 2 * np));
+    HIP_TRY(e, dev_alloc(&e->red, nm * np));
+    HIP_TRY(e, dev_alloc(&e->W2, 2 * np));
+    HIP_TRY(e, hipMemcpy(e->W2, wz_air.data(), np * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->W2 + np, wz_vapor.data(), np * sizeof(float), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -328,7 +362,8 @@ int greb_engine_destroy(greb_engine* e) {
   hipSetDevice(e->device);
   void* ptrs[] = {e->z_topo, e->glacier, e->sw_solar, e->tclim, e->qclim, e->uclim, e->vclim, e->mldclim,
                   e->cldclim, e->swetclim, e->toclim, e->z_ocean, e->wz_air, e->wz_vapor, e->state, e->acc,
-                  e->corr, e->corr_index, e->tab_index, e->tabs, e->phys, e->co2_dev, e->monthly_dev, e->yearly_dev};
+                  e->corr, e->corr_index, e->tab_index, e->tabs, e->phys, e->co2_dev, e->monthly_dev, e->yearly_dev,
+                  e->Xa, e->Xb, e->red, e->W2};
   for (void* q : ptrs) if (q) hipFree(q);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -349,7 +384,7 @@ int greb_engine_flux_correction(greb_engine* e, int years, float* yearly) {
     a.it0 = e->it_flux + 1 + (long long)y * kNT; a.nsteps = kNT;
     a.monthly = nullptr; a.monthly_years = years; a.year_out0 = y;
     a.yearly = e->yearly_dev; a.yearly_years = years; a.yearly_year0 = y;
-    HIP_TRY(e, launch_member_kernel(a, nrun, e->strict, e->stream));
+    if (int rc = run_year(e, a, nrun)) return rc;
   }
   if (e->shared_corr && e->nm > 1) { // the spun-up state (incl. cap_surf) is every member's start (A.8)
     for (int m = 1; m < e->nm; ++m)
@@ -393,7 +428,7 @@ int greb_engine_run(greb_engine* e, int years, const float* co2_ppm, float* mont
       if (dev_out) { a.monthly = monthly; a.monthly_years = years; a.year_out0 = y0 + y; }
       else { a.monthly = e->monthly_dev; a.monthly_years = chunk; a.year_out0 = y; }
       a.yearly = e->yearly_dev; a.yearly_years = years; a.yearly_year0 = y0 + y;
-      HIP_TRY(e, launch_member_kernel(a, e->nm, e->strict, e->stream));
+      if (int rc = run_year(e, a, e->nm)) return rc;
     }
     if (!dev_out) {
       HIP_TRY(e, hipMemcpy2DAsync(monthly + (size_t)y0 * rec_year, (size_t)years * rec_year * sizeof(float),

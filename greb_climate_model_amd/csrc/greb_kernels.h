@@ -58,6 +58,16 @@ hipError_t launch_circulation(const float* X, const float* wz, const float* u, c
                               float* scratch /* 3*batch*np */, const RowTables* tab_dev, const RowTables& tab_host,
                               int nx, int ny, int batch, int nsub, bool strict, hipStream_t s);
 
+// any-grid multi-launch engine (greb_kernels.hip)
+hipError_t launch_substep_fused(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
+                                const RowTables* tabs, const int* tab_index, int nx, int ny, int n_members,
+                                bool strict, hipStream_t s);
+hipError_t launch_physics_step(const MemberArgs& a, const float* X, float* Xout, float* red, int n_members,
+                               bool strict, hipStream_t s);
+hipError_t launch_yearly(const float* red, float* yearly, int np, int nx, int ipx, int ipy, int yearly_years,
+                         int year_index, int n_members, hipStream_t s);
+hipError_t launch_pack_tracers(const float* state, float* X, int np, int n_members, hipStream_t s);
+
 struct PointArgs {
   int nx, ny, np, ityr;
   float co2;

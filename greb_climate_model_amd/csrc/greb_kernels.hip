@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "greb_kernels.h"
+#include "greb_physics_step.h"
 #include "greb_stencil.h"
 
 namespace greb {
@@ -21,12 +22,15 @@ template <bool STRICT, int MODE>
 __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1, const float* __restrict__ wz,
                                                     const float* __restrict__ ug, const float* __restrict__ vg,
                                                     float* __restrict__ dX, const RowTables* __restrict__ tabp,
-                                                    int nx, int ny, int rows_per_band) {
+                                                    int nx, int ny, int rows_per_band, int wmod, int uv_shared,
+                                                    const int* __restrict__ tab_index, int tab_div) {
+  // batch item b: field T1[b]; weights wz[b % wmod] (wmod = 0: wz[b]); winds u,v[b] or shared;
+  // row tables tabp[tab_index[b / tab_div]] (tab_index = nullptr: tabp[0])
   extern __shared__ __align__(16) float lds_raw[];
   lfloat* lds = (lfloat*)lds_raw;
-  const RowTables& tab = *tabp;
-  const int nq = nx >> 2;
   const int b = blockIdx.x;
+  const RowTables& tab = tabp[tab_index ? tab_index[b / tab_div] : 0];
+  const int nq = nx >> 2;
   const int k0 = blockIdx.y * rows_per_band;
   const int k1 = min(ny, k0 + rows_per_band);
   constexpr int halo = MODE == kChainDif ? 1 : 2;
@@ -34,20 +38,23 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
   const int nrows = r1 - r0;
   lfloat* sT = lds;
   lfloat* sW = sT + nrows * nx;
-  lfloat* sU = sW + nrows * nx; // advection only: band rows k0..k1
-  lfloat* sV = sU + (MODE == kChainAdv ? (k1 - k0) * nx : 0);
-  lfloat* scratch = sV + (MODE == kChainAdv ? (k1 - k0) * nx : 0); // [nwaves][4*nx]
+  constexpr bool kWinds = MODE != kChainDif;
+  lfloat* sU = sW + nrows * nx; // with winds: band rows k0..k1
+  lfloat* sV = sU + (kWinds ? (k1 - k0) * nx : 0);
+  lfloat* scratch = sV + (kWinds ? (k1 - k0) * nx : 0); // [nwaves][4*nx]
   lfloat* rowk = scratch + 4 * 4 * nx;                              // [ny][kRowKWords]
   stage_row_consts(rowk, tab, ny);
   const size_t fo = (size_t)b * nx * ny;
+  const size_t fw = (size_t)(wmod ? b % wmod : b) * nx * ny;
+  const size_t fu = uv_shared ? 0 : fo;
   for (int i = threadIdx.x; i < nrows * nq; i += blockDim.x) {
     st4(sT + 4 * i, ld4(T1 + fo + (size_t)r0 * nx + 4 * i));
-    st4(sW + 4 * i, ld4(wz + fo + (size_t)r0 * nx + 4 * i));
+    st4(sW + 4 * i, ld4(wz + fw + (size_t)r0 * nx + 4 * i));
   }
-  if (MODE == kChainAdv)
+  if (kWinds)
     for (int i = threadIdx.x; i < (k1 - k0) * nq; i += blockDim.x) {
-      st4(sU + 4 * i, ld4(ug + fo + (size_t)k0 * nx + 4 * i));
-      st4(sV + 4 * i, ld4(vg + fo + (size_t)k0 * nx + 4 * i));
+      st4(sU + 4 * i, ld4(ug + fu + (size_t)k0 * nx + 4 * i));
+      st4(sV + 4 * i, ld4(vg + fu + (size_t)k0 * nx + 4 * i));
     }
   __syncthreads();
   const Rows X{sT, r0, nx}, W{sW, r0, nx}, U{sU, k0, nx}, V{sV, k0, nx};
@@ -70,9 +77,19 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
     float out[4];
     if (MODE == kChainDif) {
       dif_quad<STRICT>(in, rk, k, ny, out);
-    } else {
+    } else if (MODE == kChainAdv) {
       const f4 uq = ld4(U.row(k) + 4 * q), vq = ld4(V.row(k) + 4 * q);
       adv_quad<STRICT>(in, uq.v, vq.v, rk, k, ny, q == nq - 1, out);
+    } else { // fused sub-step: X_new = (X + dX_diffuse) + dX_advec, src/greb.f90:549
+      const f4 uq = ld4(U.row(k) + 4 * q), vq = ld4(V.row(k) + 4 * q);
+      float dd[4], da[4];
+      dif_quad<STRICT>(in, rk, k, ny, dd);
+      adv_quad<STRICT>(in, uq.v, vq.v, rk, k, ny, q == nq - 1, da);
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) out[i2] = in.T[4 + i2] + dd[i2] + da[i2];
+      }
     }
     st4(dX + fo + (size_t)k * nx + 4 * q, f4{{out[0], out[1], out[2], out[3]}});
   }
@@ -219,9 +236,10 @@ static int pick_band_rows(int nx, int ny, int halo, int extra_fields) {
 
 template <int MODE>
 static hipError_t launch_sweep(const float* T1, const float* wz, const float* u, const float* v, float* dX,
-                               const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s) {
+                               const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s,
+                               int wmod = 0, int uv_shared = 0, const int* tab_index = nullptr, int tab_div = 1) {
   constexpr int halo = MODE == kChainDif ? 1 : 2;
-  constexpr int extra = MODE == kChainAdv ? 2 : 0;
+  constexpr int extra = MODE == kChainDif ? 0 : 2;
   const int rows = pick_band_rows(nx, ny, halo, extra);
   const int bands = (ny + rows - 1) / rows;
   const size_t lds = sweep_lds_bytes(nx, rows, halo, extra);
@@ -230,7 +248,7 @@ static hipError_t launch_sweep(const float* T1, const float* wz, const float* u,
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, block, lds, s, T1, wz, u, v, dX, tab_dev, nx, ny, rows);
+  hipLaunchKernelGGL(kern, grid, block, lds, s, T1, wz, u, v, dX, tab_dev, nx, ny, rows, wmod, uv_shared, tab_index, tab_div);
   return hipGetLastError();
 }
 
@@ -315,6 +333,86 @@ __global__ void point_kernel(PointArgs a) {
 
 hipError_t launch_point_physics(const PointArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(point_kernel, dim3((a.np + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Any-grid ("multi-launch") engine pieces for grids whose member does not fit one CU's LDS
+// (384x192: 295 KB per field).  One launch per circulation sub-step over (member x tracer) x
+// latitude bands, one launch per model step for the point physics, one per year for the
+// diagnostic global mean.  Same device functions as the fused 96x48 engine.
+// ============================================================================================
+hipError_t launch_substep_fused(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
+                                const RowTables* tabs, const int* tab_index, int nx, int ny, int n_members,
+                                bool strict, hipStream_t s) {
+  // batch = n_members x {Tair, q}; weights W2[2] = {wz_air, wz_vapor}; winds shared by everyone
+  return launch_sweep<kChainFused>(X, W2, u, v, Xnew, tabs, nx, ny, 2 * n_members, strict, s, 2, 1, tab_index, 2);
+}
+
+template <bool STRICT, bool FLUX>
+__global__ __launch_bounds__(256) void physics_step_kernel(MemberArgs a, const float* __restrict__ X,
+                                                           float* __restrict__ Xout, float* __restrict__ red) {
+  const int m = blockIdx.y, np = a.np;
+  const int qd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qd >= np / 4) return;
+  const StepClock ck = step_clock<FLUX>(a, a.it0, np);
+  const Phys P = a.phys[m];
+  const float co2 = FLUX ? a.co2_flux : a.co2[(size_t)m * a.co2_stride + a.co2_year0];
+  float* state = a.state + (size_t)m * 5 * np;
+  float* acc = a.acc + (size_t)m * 6 * np;
+  float* corr = a.corr + (size_t)a.corr_index[m] * 3 * kNT * np;
+  const f4 xTa = ld4(X + ((size_t)m * 2) * np + 4 * qd), xq = ld4(X + ((size_t)m * 2 + 1) * np + 4 * qd);
+  f4 oTa, oq, tsm;
+  physics_quad<STRICT, FLUX>(a, P, m, qd, ck, co2, state, acc, corr, xTa, xq, oTa, oq, tsm);
+  st4(Xout + ((size_t)m * 2) * np + 4 * qd, oTa);
+  st4(Xout + ((size_t)m * 2 + 1) * np + 4 * qd, oq);
+  if (ck.ityr == kNT) st4(red + (size_t)m * np + 4 * qd, tsm);
+}
+
+hipError_t launch_physics_step(const MemberArgs& a, const float* X, float* Xout, float* red, int n_members,
+                               bool strict, hipStream_t s) {
+  void (*kern)(MemberArgs, const float*, float*, float*);
+  if (a.flux_phase) kern = strict ? physics_step_kernel<true, true> : physics_step_kernel<false, true>;
+  else kern = strict ? physics_step_kernel<true, false> : physics_step_kernel<false, false>;
+  hipLaunchKernelGGL(kern, dim3((a.np / 4 + 255) / 256, n_members), dim3(256), 0, s, a, X, Xout, red);
+  return hipGetLastError();
+}
+
+// diagnostics at the end of a model year (src/greb.f90:948-954): the reference's sum() is a
+// sequential fp32 loop; one thread per member reproduces that order
+__global__ void yearly_kernel(const float* __restrict__ red, float* __restrict__ yearly, int np, int nx, int ipx,
+                              int ipy, int yearly_years, int year_index, int n_members) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_members) return;
+  {
+#pragma clang fp contract(off)
+    const float* r = red + (size_t)m * np;
+    float sum = 0.f;
+    for (int i = 0; i < np; ++i) sum += r[i];
+    float* y = yearly + ((size_t)m * yearly_years + year_index) * 2;
+    y[0] = sum / (float)np - 273.15f;
+    y[1] = r[(ipy - 1) * nx + (ipx - 1)] - 273.15f;
+  }
+}
+
+hipError_t launch_yearly(const float* red, float* yearly, int np, int nx, int ipx, int ipy, int yearly_years,
+                         int year_index, int n_members, hipStream_t s) {
+  hipLaunchKernelGGL(yearly_kernel, dim3((n_members + 63) / 64), dim3(64), 0, s, red, yearly, np, nx, ipx, ipy,
+                     yearly_years, year_index, n_members);
+  return hipGetLastError();
+}
+
+__global__ void pack_tracers_kernel(const float* __restrict__ state, float* __restrict__ X, int np, int n_members) {
+  // X[m][0] = Tair = state[m][1], X[m][1] = q = state[m][3]
+  const size_t n = (size_t)n_members * 2 * np;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / (2 * (size_t)np), r = i % (2 * (size_t)np);
+    const int tr = (int)(r / np);
+    X[i] = state[m * 5 * np + (size_t)(tr ? 3 : 1) * np + r % np];
+  }
+}
+hipError_t launch_pack_tracers(const float* state, float* X, int np, int n_members, hipStream_t s) {
+  hipLaunchKernelGGL(pack_tracers_kernel, dim3(1024), dim3(256), 0, s, state, X, np, n_members);
   return hipGetLastError();
 }
 

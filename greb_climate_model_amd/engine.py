@@ -65,7 +65,7 @@ class Engine:
     qflux_correction (src/greb.f90:311-364), run() is the scenario loop (:228-234)."""
 
     def __init__(self, inp: workload.Inputs, params: abi.GrebParams | None = None, n_members: int = 1,
-                 overrides=None, device: int = 0, strict: bool = False):
+                 overrides=None, device: int = 0, strict: bool = False, multilaunch: bool = False):
         L = lib()
         self.params = params or params_default()
         self.nx, self.ny, self.np, self.nm = inp.nx, inp.ny, inp.nx * inp.ny, n_members
@@ -78,7 +78,7 @@ class Engine:
                     setattr(ov[i], k, float(o.get(k, float("nan"))))
         self.h = C.c_void_p()
         rc = L.greb_engine_create(C.byref(self.params), inp.nx, inp.ny, C.byref(fields), n_members, ov, device,
-                                  abi.F_STRICT if strict else 0, C.byref(self.h))
+                                  (abi.F_STRICT if strict else 0) | (abi.F_MULTILAUNCH if multilaunch else 0), C.byref(self.h))
         if rc != 0:
             msg = L.greb_engine_last_error(self.h).decode()
             if self.h:

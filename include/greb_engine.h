@@ -77,10 +77,15 @@ typedef struct greb_member_overrides {
 /* engine flags */
 #define GREB_F_STRICT 1u /* reference operation order, IEEE division, no FMA contraction
                             (bit-exact stencils; default is the restructured fast arithmetic) */
+#define GREB_F_MULTILAUNCH 2u /* force the any-grid engine (one launch per circulation sub-step) even
+                                 where the fused one-CU-per-member kernel applies (96x48); grids that
+                                 do not fit one CU, e.g. 384x192, always use it */
 
 typedef struct greb_engine greb_engine;
 
 /* Create an engine for n_members ensemble members on HIP device `device`.
+ * Any grid with nx % 4 == 0, ny <= 192: 96x48 runs the fused member kernel (whole member resident
+ * in one CU), other grids the multi-launch engine.
  * Copies the inputs to HBM, computes the derived fields of greb_model's preamble
  * (src/greb.f90:176-216) and Toclim (src/greb.f90:1088-1094) and sets every member's
  * state to the initial state (src/greb.f90:194-197).  overrides may be NULL. */

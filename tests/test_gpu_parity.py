@@ -217,3 +217,36 @@ def test_perturbed_physics_members(eng_mod, params, inputs, oracle_lib):
         o.close()
     assert rms(mon[1], mon[0]) > 1e-3  # the perturbation does something
     e.close()
+
+
+# ------------------------------------------------------------------------------------ any-grid engine
+@pytest.mark.parametrize("strict", [True, False])
+def test_multilaunch_engine_g96_vs_reference(eng_mod, params, inputs, strict):
+    """The any-grid (multi-launch) engine forced onto 96x48: same 1+2-yr run, same tolerances."""
+    g = load_golden("run_short_g96.npz")
+    e = eng_mod.Engine(inputs, params, strict=strict, multilaunch=True)
+    yf = e.flux_correction(1)
+    mon, yr = e.run(2, 680.0)
+    _check_run(mon[0].reshape(24, 5, 48, 96), g["monthly"], "ml-" + ("strict" if strict else "fast"))
+    assert np.abs(np.concatenate([yf[0], yr[0]]) - g["yearly"]).max() < 2e-3
+    e.close()
+
+
+def test_engine_g384_vs_oracle(eng_mod, oracle_lib):
+    """BASELINE config 3's grid: 384x192 (bilinear-upsampled inputs), 1 flux-correction year + 1
+    scenario year, STRICT, 2 members (CO2 340 / 680) against the oracle at the same grid.  Every row
+    is sub-cycled (up to 225 sweeps); the two polar rows keep the reference's inherited
+    time2 = 1, ccx2 = 0 behaviour."""
+    from greb_climate_model_amd import abi, workload
+    inp = workload.make_inputs(384, 192)
+    p = abi.default_params(ipx=380, ipy=150)
+    e = eng_mod.Engine(inp, p, n_members=2, strict=True)
+    yf = e.flux_correction(1)
+    mon, yr = e.run(1, np.asarray([[340.0], [680.0]], np.float32))
+    o = oracle_lib.Oracle(inp, p)
+    yfo = o.flux_correction(1)
+    ref, yro = o.run(1, 680.0)
+    _check_run(mon[1, 0], ref[0], "g384")
+    assert np.abs(yf[1] - yfo).max() < 2e-3 and np.abs(yr[1] - yro).max() < 2e-3
+    assert rms(mon[0, 0, 11, 0], mon[1, 0, 11, 0]) > 1e-2  # the members differ (CO2)
+    o.close(); e.close()
