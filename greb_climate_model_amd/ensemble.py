@@ -41,3 +41,22 @@ def gather_monthly(local, n_members: int, group=None):
     if rank != 0:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def ensemble_stats(local, group=None):
+    """On-device ensemble mean and (population) variance of per-member fields across ALL ranks
+    (SURVEY.md 8f-4): two all-reduces (RCCL on the node) of the member-sum and member-sum-of-squares,
+    accumulated in fp64 so the result does not depend on how members are dealt to ranks.
+    local: [m_local, ...] -> (mean[...], var[...]) on every rank."""
+    import torch
+    import torch.distributed as dist
+    x = local.to(torch.float64)
+    s1 = x.sum(0)
+    s2 = (x * x).sum(0)
+    n = torch.tensor([float(local.shape[0])], dtype=torch.float64, device=local.device)
+    if dist.is_available() and dist.is_initialized():
+        for t in (s1, s2, n):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    mean = s1 / n
+    var = (s2 / n - mean * mean).clamp_min(0.0)
+    return mean.to(local.dtype), var.to(local.dtype)

@@ -35,6 +35,9 @@ def _worker(rank, world, port, n_members, q):
         local = torch.stack([torch.full((2, 12, 5, 8), float(i)) + torch.arange(8.0) for i in ids]) \
             if len(ids) else torch.zeros((0, 2, 12, 5, 8))
         out = ensemble.gather_monthly(local, n_members)
+        mean, var = ensemble.ensemble_stats(local)
+        full = torch.stack([torch.full((2, 12, 5, 8), float(i)) + torch.arange(8.0) for i in range(n_members)])
+        assert torch.allclose(mean, full.mean(0), atol=1e-6) and torch.allclose(var, full.var(0, unbiased=False), atol=1e-5)
         if rank == 0:
             ok = out.shape[0] == n_members and all(
                 torch.equal(out[i], torch.full((2, 12, 5, 8), float(i)) + torch.arange(8.0)) for i in range(n_members))

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Run one of BASELINE.json's configurations on the MI355X engine and print a JSON summary.
+
+  python tools/run_config.py 2            single MI355X, 1 member, default 2xCO2 3+50 yr, vs the reference's
+                                          golden statistics (tests/golden/run_default_g96.npz)
+  python tools/run_config.py 3 [--years Y]  384x192 (bilinear-upsampled inputs), 1 member, 3+Y yr (default 50)
+  python tools/run_config.py 4 [--years Y]  8 CO2 levels 280..1120 ppm, 3+Y yr (default 100); one process per GPU
+                                          under torchrun (members dealt to ranks, RCCL gather), or all 8 on one GPU
+  python tools/run_config.py 5 [--years Y] [--members M]  64 perturbed-physics members (da_ice, a_no_ice, a_cloud,
+                                          kappa +-10 %, SplitMix64 seed 20261004), 384x192, 3+Y yr (default 50)
+Config 1 is the reference Fortran on the CPU (oracle/_ref/greb_ref; bench.py times it as cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def splitmix64(seed, n):
+    """Deterministic uniforms in [0,1): SplitMix64."""
+    out, x, M = [], seed & (2**64 - 1), 2**64 - 1
+    for _ in range(n):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        out.append((z >> 11) / float(1 << 53))
+    return np.asarray(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", type=int, choices=[2, 3, 4, 5])
+    ap.add_argument("--years", type=int, default=None)
+    ap.add_argument("--members", type=int, default=None)
+    ap.add_argument("--strict", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from greb_climate_model_amd import abi, engine, ensemble, workload
+
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = args.config
+    g384 = cfg in (3, 5)
+    inp = workload.make_inputs(384, 192) if g384 else workload.make_inputs()
+    p = engine.params_default()
+    p.ipx, p.ipy = (380, 150) if g384 else (95, 38)
+    tf = 3
+    years = args.years or {2: 50, 3: 50, 4: 100, 5: 50}[cfg]
+    n_total = {2: 1, 3: 1, 4: 8, 5: args.members or 64}[cfg]
+    ids = ensemble.partition(n_total, world, rank)
+    overrides, co2 = None, np.full((len(ids), years), 680.0, np.float32)
+    if cfg == 4:
+        co2 = np.repeat(ensemble.co2_sweep(8)[ids][:, None], years, 1)
+    if cfg == 5:
+        u = splitmix64(20261004, 4 * n_total).reshape(n_total, 4)
+        base = dict(da_ice=p.da_ice, a_no_ice=p.a_no_ice, a_cloud=p.a_cloud, kappa=p.kappa)
+        overrides = [{k: float(np.float32(base[k] * (0.9 + 0.2 * u[g, j]))) for j, k in enumerate(base)} for g in ids]
+    out = {"config": cfg, "grid": [inp.nx, inp.ny], "members_total": n_total, "members_this_rank": len(ids),
+           "time_flux": tf, "time_scnr": years, "n_gpus": world, "arithmetic": "strict" if args.strict else "fast"}
+    t0 = time.perf_counter()
+    e = engine.Engine(inp, p, n_members=len(ids), overrides=overrides, device=local_rank, strict=args.strict)
+    yf = e.flux_correction(tf)
+    t1 = time.perf_counter()
+    mon_dev = torch.empty((len(ids), years, 12, 5, e.np), dtype=torch.float32, device="cuda")
+    _, yr = e.run(years, co2, monthly_dev_ptr=mon_dev.data_ptr())
+    gathered = ensemble.gather_monthly(mon_dev, n_total) if world > 1 else mon_dev
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    out.update(flux_phase_s=round(t1 - t0, 3), scenario_s=round(t2 - t1, 3),
+               member_years_per_s=round(n_total * (tf + years) / (t2 - t0), 2),
+               scenario_member_years_per_s=round(n_total * years / (t2 - t1), 2))
+    if rank == 0:
+        m = gathered.reshape(n_total, years * 12, 5, inp.ny, inp.nx)
+        out["finite"] = bool(torch.isfinite(m).all())
+        out["last_year_global_mean_tsurf_C"] = [round(float(x), 4) for x in yr[:, -1, 0]]
+        out["last_december_mean"] = {k: round(float(m[0, -1, i].double().mean()), 6)
+                                     for i, k in enumerate(("Tsurf", "Tair", "Tocean", "q", "albedo"))}
+        if cfg == 2:  # compare with the reference Fortran's statistics for the same namelist
+            with np.load(os.path.join(ROOT, "tests", "golden", "run_default_g96.npz")) as z:
+                stats, sel, months, yref = z["stats"], z["monthly_sel"], z["months"], z["yearly"]
+            mine = m[0].double().mean((2, 3)).cpu().numpy()
+            out["max_abs_diff_of_monthly_field_means_vs_reference"] = [float(np.abs(mine[:, i] - stats[:, i, 0]).max()) for i in range(5)]
+            full = m[0][[int(k) - 1 for k in months]].cpu().numpy().astype(np.float64)
+            out["rms_vs_reference_months_1_12_300_600"] = [float(np.sqrt(((full[:, i] - sel[:, i]) ** 2).mean())) for i in range(5)]
+            out["max_abs_diff_yearly_console_values"] = float(np.abs(np.concatenate([yf[0], yr[0]]) - yref).max())
+        print(json.dumps(out))
+    e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
