@@ -124,8 +124,8 @@ __global__ __launch_bounds__(kStreamThreads) void diffusion_stream_kernel(const 
   lfloat* lds = (lfloat*)lds_raw;
   lfloat* sT = lds;
   lfloat* sW = sT + ny * nx;
-  lfloat* scratch = sW + ny * nx;      // [2 halves][4*nx]
-  lfloat* rowk = scratch + 2 * 4 * nx; // [ny][kRowKWords]
+  lfloat* scratch = sW + ny * nx;      // [2 halves][2*nx]: diffusion chains use two row buffers each
+  lfloat* rowk = scratch + 2 * 2 * nx; // [ny][kRowKWords]
   lfloat* chainlist = rowk + ny * kRowKWords; // [ny] row indices of the chain rows
   stage_row_consts(rowk, *tabp, ny);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kStreamThreads) void diffusion_stream_kernel(const 
           if (ci < nchain) {
             const int k = __float_as_int(chainlist[ci]);
             chain_row<STRICT>(X, W, X, X, row_consts((const lfloat*)rowk, k), k, nq, ny, ql, kChainDif,
-                              scratch + half * 4 * nx, out + (size_t)k * nx);
+                              scratch + half * 2 * nx, out + (size_t)k * nx);
           }
         }
       }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kStreamThreads) void diffusion_stream_kernel(const 
   }
 }
 
-static size_t stream_lds_bytes(int nx, int ny) { return (size_t)(2 * nx * ny + 2 * 4 * nx + ny * kRowKWords + ny) * sizeof(float); }
+static size_t stream_lds_bytes(int nx, int ny) { return (size_t)(2 * nx * ny + 2 * 2 * nx + ny * kRowKWords + ny) * sizeof(float); }
 static bool stream_fits(int nx, int ny) { return nx == 96 && ny == 48; }
 
 static size_t sweep_lds_bytes(int nx, int rows, int halo, int extra_fields) {
