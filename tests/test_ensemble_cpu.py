@@ -58,3 +58,36 @@ def test_gather_monthly_world2(n_members):
     for p in procs: p.join(120)
     assert all(p.exitcode == 0 for p in procs)
     assert q.get(timeout=5) is True
+
+
+def _worker_pipeline(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        M, K = 3, 4
+        g = ensemble.MonthlyGather(M, K, (12, 5, 8), torch.float32, "cpu")
+        keep = []
+        for y in range(K):  # member id and year encoded in the data
+            t = torch.stack([torch.full((12, 5, 8), float(100 * (rank * M + i) + y)) for i in range(M)])
+            keep.append(t)
+            g.submit(y, t)
+        out = g.finish()
+        if rank == 0:
+            ok = tuple(out.shape) == (world * M, K, 12, 5, 8) and all(
+                float(out[mm, y, 0, 0, 0]) == 100 * mm + y for mm in range(world * M) for y in range(K))
+            q.put(bool(ok))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_monthly_gather_pipeline_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_pipeline, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) is True
