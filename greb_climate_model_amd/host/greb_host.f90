@@ -13,7 +13,8 @@
 !   * the console trace                                (src/greb.f90:219,224-225,941,954,1070)
 ! Control crosses into the engine twice per run (flux-correction phase, scenario phase); the
 ! derived fields of greb_model's preamble are computed by the engine's create().
-! An optional fifth group &ENGINE_PAR (strict, device) selects reference-order arithmetic / GPU.
+! An optional fifth group &ENGINE_PAR (strict, device, corr_file) selects reference-order arithmetic,
+! the GPU, and a flux-correction cache file.
 module greb_c_api
   use iso_c_binding
   implicit none
@@ -58,6 +59,20 @@ module greb_c_api
        integer(c_int), value :: years, run_flags
        real(c_float), intent(in) :: co2_ppm(*)
        real(c_float), intent(out) :: monthly(*), yearly(*)
+     end function
+     integer(c_int) function greb_engine_get_corrections(eng, member, corr, state5) &
+          bind(C, name="greb_engine_get_corrections")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: eng
+       integer(c_int), value :: member
+       real(c_float), intent(out) :: corr(*), state5(*)
+     end function
+     integer(c_int) function greb_engine_set_corrections(eng, member, corr, state5) &
+          bind(C, name="greb_engine_set_corrections")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: eng
+       integer(c_int), value :: member
+       real(c_float), intent(in) :: corr(*), state5(*)
      end function
      integer(c_int) function greb_engine_destroy(eng) bind(C, name="greb_engine_destroy")
        import :: c_int, c_ptr
@@ -109,15 +124,17 @@ program greb_host
   integer :: ipx, ipy, time_flux, time_scnr, year0
   character(len=120) :: output_file
   character(len=10)  :: ens_id
-  logical :: strict
+  logical :: strict, have_cache
   integer :: device
+  character(len=200) :: corr_file
+  real(c_float), allocatable :: corr(:), state5(:)
   namelist / physics_par / pi, sig, rho_ocean, rho_land, rho_air, cp_ocean, cp_land, cp_air, eps, &
        d_ocean, d_land, d_air, ct_sens, da_ice, a_no_ice, a_cloud, Tl_ice1, Tl_ice2, To_ice1, To_ice2, &
        co_turb, kappa, ce, cq_latent, cq_rain, z_air, z_vapor, r_qviwv, p_emi
   namelist / numerics_par / ipx, ipy, time_flux, time_scnr, year0
   namelist / diagnostics_par / output_file, ens_id
   namelist / co2_par / co2_ppm, co2_flux
-  namelist / engine_par / strict, device
+  namelist / engine_par / strict, device, corr_file
 
   type(greb_params) :: prm
   type(greb_fields) :: fld
@@ -145,7 +162,7 @@ program greb_host
   co2_flux = prm%co2_flux
   ipx = 1; ipy = 1; time_flux = 0; time_scnr = 0; year0 = 1940
   output_file = 'output/scenario'; ens_id = ''
-  strict = .false.; device = 0
+  strict = .false.; device = 0; corr_file = ''
 
   nargs = command_argument_count()
   nml_file = 'namelist'
@@ -210,14 +227,48 @@ program greb_host
   rc = greb_engine_create(prm, nx, ny, fld, 1, c_null_ptr, int(device, c_int), flags, eng)
   call engine_check(rc, eng, 'greb_engine_create')
 
-  print*,'% FLUX CORRECTION RUN; years = ', time_flux, ' co2 = ', co2_flux
-  allocate(yflux(2*max(time_flux,1)))
-  rc = greb_engine_flux_correction(eng, int(time_flux, c_int), yflux)
-  call engine_check(rc, eng, 'greb_engine_flux_correction')
-  if (time_flux > 0) print *, 'console output: year, co2, global avg temp, avg temp for ipx/ipy'
-  do n = 1, time_flux
-     print *, 0.0, co2_flux, yflux(2*n-1), yflux(2*n)
-  end do
+  ! Flux-correction cache (SURVEY.md 8f-2): the reference recomputes qflux_correction
+  ! (src/greb.f90:311-364) in every run.  With corr_file set, the phase's products -- TF/qF/ToF_correct,
+  ! cap_surf and the end state -- are written after the first run and read back by later ones, which
+  ! then start the scenario directly (same records as every other GREB file: nx*ny fp32 each).
+  have_cache = .false.
+  if (len_trim(corr_file) > 0) inquire(file=trim(corr_file), exist=have_cache)
+  if (len_trim(corr_file) > 0) allocate(corr(3*nstep*nx*ny), state5(5*nx*ny))
+  if (have_cache) then
+     print*,'% FLUX CORRECTION read from ', trim(corr_file)
+     open(23, file=trim(corr_file), access='direct', form='unformatted', recl=4*nx*ny, status='old')
+     do irec = 1, 3*nstep
+        read(23, rec=irec) corr((irec-1)*nx*ny+1 : irec*nx*ny)
+     end do
+     do irec = 1, 5
+        read(23, rec=3*nstep+irec) state5((irec-1)*nx*ny+1 : irec*nx*ny)
+     end do
+     close(23)
+     rc = greb_engine_set_corrections(eng, -1_c_int, corr, state5)
+     call engine_check(rc, eng, 'greb_engine_set_corrections')
+  else
+     print*,'% FLUX CORRECTION RUN; years = ', time_flux, ' co2 = ', co2_flux
+     allocate(yflux(2*max(time_flux,1)))
+     rc = greb_engine_flux_correction(eng, int(time_flux, c_int), yflux)
+     call engine_check(rc, eng, 'greb_engine_flux_correction')
+     if (time_flux > 0) print *, 'console output: year, co2, global avg temp, avg temp for ipx/ipy'
+     do n = 1, time_flux
+        print *, 0.0, co2_flux, yflux(2*n-1), yflux(2*n)
+     end do
+     if (len_trim(corr_file) > 0) then
+        rc = greb_engine_get_corrections(eng, 0_c_int, corr, state5)
+        call engine_check(rc, eng, 'greb_engine_get_corrections')
+        open(23, file=trim(corr_file), access='direct', form='unformatted', recl=4*nx*ny)
+        do irec = 1, 3*nstep
+           write(23, rec=irec) corr((irec-1)*nx*ny+1 : irec*nx*ny)
+        end do
+        do irec = 1, 5
+           write(23, rec=3*nstep+irec) state5((irec-1)*nx*ny+1 : irec*nx*ny)
+        end do
+        close(23)
+        print*,'% FLUX CORRECTION saved in ', trim(corr_file)
+     end if
+  end if
 
   print*,'% MODEL RUN; years = ', time_scnr
   print*,'% saving output in file ', out_full

@@ -40,3 +40,27 @@ def test_host_reproduces_reference_output(tmp_path, inputs, strict):
     rows = [[float(x) for x in l.split()] for l in lines if len(l.split()) == 4 and l.split()[0][0].isdigit()]
     assert len(rows) == 3 and [r_[0] for r_ in rows] == [0.0, 1940.0, 1941.0] and rows[1][1] == 680.0
     assert np.abs(np.asarray(rows)[:, 2:] - g["yearly"]).max() < 2e-3
+
+
+def test_host_flux_correction_cache(tmp_path, inputs):
+    """with &ENGINE_PAR corr_file the first run saves the flux-correction phase's products
+    (3x730 correction records + cap_surf + the four state fields) and a later run reads them instead of
+    integrating the phase again.  Both scenario outputs must be identical bit for bit."""
+    from greb_climate_model_amd import build, workload
+    host = os.path.join(build.PKG, "greb_host")
+    if not os.path.exists(host):
+        pytest.skip("greb_host not built (no Fortran compiler at build time)")
+    inputs.write_input_dir(str(tmp_path / "input"))
+    os.makedirs(tmp_path / "output")
+    outs = []
+    for k, ens in enumerate(("a", "b")):
+        workload.write_namelist(str(tmp_path / "namelist"), 1, 1, (560.0,), 95, 38, ens_id=ens)
+        with open(tmp_path / "namelist", "a") as f:
+            f.write("&ENGINE_PAR\n  corr_file = 'output/flux_cache'\n/\n")
+        r = subprocess.run([host], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ("% FLUX CORRECTION read from" in r.stdout) == (k == 1), r.stdout
+        assert ("% FLUX CORRECTION RUN" in r.stdout) == (k == 0), r.stdout
+        outs.append(np.fromfile(tmp_path / "output" / f"scenario_{ens}", dtype="<f4"))
+    assert os.path.getsize(tmp_path / "output" / "flux_cache") == (3 * 730 + 5) * 96 * 48 * 4
+    assert outs[0].size == 96 * 48 * 5 * 12 and np.array_equal(outs[0], outs[1])
