@@ -37,6 +37,8 @@ struct greb_oracle {
   long it_scnr; /* steps done in the scenario so far */
   float year;   /* src/greb.f90:227,233 (implicitly typed REAL) */
   oracle_grid g;
+  int log_exp; /* greb.original.model.f90:60; 10 = complete model = src/greb.f90 */
+  int scenario; /* 1 inside the original's scenario loop (SST+1 applies there only, :224-226) */
   /* scratch */
   float *scr;
 };
@@ -144,6 +146,7 @@ greb_oracle* oracle_create(const greb_params* p, int nx, int ny, const greb_fiel
     o->To[i] = o->toclim2d[i];     o->q[i] = o->qclim[last + i];
   }
   o->mon = 1; o->it_scnr = 0; o->year = (float)p->year0; /* :227 */
+  o->log_exp = 10; o->scenario = 1;
   return o;
 }
 
@@ -359,6 +362,23 @@ void oracle_circulation_uv(const greb_oracle* o, const float* u, const float* v,
   free(X);
 }
 
+/* circulation() of the original with log_exp == 8 for the vapour call: diffusion sub-steps only
+ * (greb.original.model.f90:560-564) */
+static void oracle_diffusion_only(const greb_oracle* o, const float* X_in, float* dX, const float* wz) {
+  const int np = o->np;
+  int time = nint_f((float)o->p.dt / (float)o->p.dt_crcl);
+  if (time < 1) time = 1;
+  float* X = (float*)malloc(sizeof(float) * 2 * np);
+  float* dd = X + np;
+  memcpy(X, X_in, sizeof(float) * np);
+  for (int tt = 0; tt < time; ++tt) {
+    oracle_diffusion(o, X, dd, wz);
+    for (int i = 0; i < np; ++i) X[i] = X[i] + dd[i];
+  }
+  for (int i = 0; i < np; ++i) dX[i] = X[i] - X_in[i];
+  free(X);
+}
+
 void oracle_circulation(const greb_oracle* o, int ityr, const float* X_in, float* dX, const float* wz) {
   const size_t off = (size_t)(ityr - 1) * o->np;
   oracle_circulation_uv(o, o->uclim + off, o->vclim + off, X_in, dX, wz);
@@ -390,6 +410,7 @@ void oracle_swradiation(const greb_oracle* o, int ityr, const float* Ts, float* 
           a_surf = p->a_no_ice + p->da_ice * (1.f - (T - p->To_ice1) / (p->To_ice2 - p->To_ice1));
       }
       if (o->glacier[i] > 0.5f) a_surf = p->a_no_ice + p->da_ice; /* :395 */
+      if (o->log_exp <= 5) a_surf = p->a_no_ice;                  /* greb.original.model.f90:394 */
       albedo[i] = a_surf + a_atmos - a_surf * a_atmos;            /* :398 */
       sw[i] = sol[k] * (1.f - albedo[i]);                         /* :400 */
     }
@@ -407,12 +428,14 @@ void oracle_lwradiation(const greb_oracle* o, int ityr, const float* Ts, const f
   for (int i = 0; i < o->np; ++i) {
     const float ez = expf(-o->z_topo[i] / p->z_air);
     const float e_co2 = ez * co2;              /* :420 */
-    const float e_vapor = ez * p->r_qviwv * q[i]; /* :421 */
+    float e_vapor = ez * p->r_qviwv * q[i]; /* :421 */
+    if (o->log_exp == 11) e_vapor = ez * p->r_qviwv * o->qclim[off + i]; /* greb.original.model.f90:423 */
     const float e_cloud = o->cldclim[off + i]; /* :422 */
     float e = pe[3] * logf(pe[0] * e_co2 + pe[1] * e_vapor + pe[2]) + pe[6]
               + pe[4] * logf(pe[0] * e_co2 + pe[2])
               + pe[5] * logf(pe[1] * e_vapor + pe[2]); /* :425-427 */
     e = (pe[7] - e_cloud) / pe[8] * (e - pe[9]) + pe[9]; /* :428 */
+    if (o->log_exp == 11) e = e + 0.022f / (0.15f * 24.f) * p->r_qviwv * (q[i] - o->qclim[off + i]); /* orig :430 */
     em[i] = e;
     LWsurf[i] = -p->sig * pow4(Ts[i]);                                   /* :430 */
     const float dTrad = -0.16f * o->tclim[off + i] - 5.f;                /* :176 */
@@ -426,6 +449,10 @@ void oracle_hydro(const greb_oracle* o, int ityr, const float* Ts, const float* 
                   float* Qlat_air, float* dq_eva, float* dq_rain) {
   const greb_params* p = &o->p;
   const size_t off = (size_t)(ityr - 1) * o->np;
+  if (o->log_exp <= 6 || o->log_exp == 13 || o->log_exp == 15) { /* greb.original.model.f90:452-453 */
+    for (int i = 0; i < o->np; ++i) Qlat[i] = Qlat_air[i] = dq_eva[i] = dq_rain[i] = 0.f;
+    return;
+  }
   for (int i = 0; i < o->np; ++i) {
     const float u = o->uclim[off + i], v = o->vclim[off + i];
     float abswind = sqrtf(u * u + v * v);                                  /* :452 */
@@ -453,6 +480,10 @@ void oracle_seaice(greb_oracle* o, int ityr, const float* Ts) {
         o->cap_surf[i] = o->cap_land + (o->cap_ocean * mld[i] - o->cap_land)
                                            / (p->To_ice2 - p->To_ice1) * (T - p->To_ice1);
     }
+    if (o->log_exp <= 5) { /* greb.original.model.f90:492-495 */
+      if (o->z_topo[i] > 0.f) o->cap_surf[i] = o->cap_land;
+      if (o->z_topo[i] < 0.f) o->cap_surf[i] = o->cap_ocean * mld[i];
+    }
     if (o->glacier[i] > 0.5f) o->cap_surf[i] = o->cap_land;            /* :490 */
   }
 }
@@ -464,6 +495,10 @@ void oracle_deep_ocean(const greb_oracle* o, int ityr, const float* Ts, const fl
   const float* mld = o->mldclim + (size_t)(ityr - 1) * o->np;
   const float* mldm = o->mldclim + (size_t)(ityr > 1 ? ityr - 2 : NT - 1) * o->np; /* :507-508 */
   const float dt = (float)p->dt;
+  if (o->log_exp <= 9 || o->log_exp == 11 || (o->log_exp >= 14 && o->log_exp <= 16)) { /* orig :513-515 */
+    for (int i = 0; i < o->np; ++i) dT_ocean[i] = dTo[i] = 0.f;
+    return;
+  }
   for (int i = 0; i < o->np; ++i) {
     float a = 0.f, b = 0.f; /* dTo, dT_ocean :505 */
     const float dmld = mld[i] - mldm[i];
@@ -501,8 +536,13 @@ static void tendencies(greb_oracle* o, int ityr, float co2, const tend_t* t) {
   oracle_lwradiation(o, ityr, o->Ts, o->Ta, o->q, co2, t->LW_surf, t->LWair_up, t->LWair_down, t->em); /* :293 */
   for (int i = 0; i < o->np; ++i) t->Q_sens[i] = o->p.ct_sens * (o->Ta[i] - o->Ts[i]);    /* :295 */
   oracle_hydro(o, ityr, o->Ts, o->q, t->Q_lat, t->Q_lat_air, t->dq_eva, t->dq_rain);     /* :297 */
-  oracle_circulation(o, ityr, o->Ta, t->dTa_crcl, o->wz_air);                             /* :301 */
-  oracle_circulation(o, ityr, o->q, t->dq_crcl, o->wz_vapor);                             /* :303 */
+  /* greb.original.model.f90:553-571.  Where the original returns before assigning dX_crcl (log_exp <= 4; the
+   * vapour call at 7 and 16) its intent(out) result is undefined; defined here as no transport (0). */
+  if (o->log_exp <= 4) memset(t->dTa_crcl, 0, sizeof(float) * o->np);
+  else oracle_circulation(o, ityr, o->Ta, t->dTa_crcl, o->wz_air);                        /* :301 */
+  if (o->log_exp <= 4 || o->log_exp == 7 || o->log_exp == 16) memset(t->dq_crcl, 0, sizeof(float) * o->np);
+  else if (o->log_exp == 8) oracle_diffusion_only(o, o->q, t->dq_crcl, o->wz_vapor);     /* orig :560-564 */
+  else oracle_circulation(o, ityr, o->q, t->dq_crcl, o->wz_vapor);                        /* :303 */
   oracle_deep_ocean(o, ityr, o->Ts, o->To, t->dT_ocean, t->dTo);                          /* :306 */
 }
 
@@ -600,6 +640,13 @@ void oracle_run(greb_oracle* o, int years, const float* co2_ppm, float* monthly,
     const int jday = (int)(((it - 1) / 2) % 365) + 1; /* :251 */
     const int ityr = (int)((it - 1) % NT) + 1;        /* :252 */
     const size_t off = (size_t)(ityr - 1) * np;
+    if (o->scenario && o->log_exp >= 14 && o->log_exp <= 16) {
+      /* sens. exp. SST+1, greb.original.model.f90:226 (CO2 = CO2_ctrl: the caller's series).  The statement sits
+       * BEFORE time_loop updates the module variable ityr (:247), so it reads the climatology slice of the
+       * PREVIOUS step -- slice 730 at it = 1, left there by the preceding phase. */
+      const size_t offp = (size_t)((it - 2 + NT) % NT) * np;
+      for (int i = 0; i < np; ++i) if (o->z_topo[i] < 0.0f) o->Ts[i] = o->tclim[offp + i] + 1.0f;
+    }
     tendencies(o, ityr, co2, &t);                      /* :254 */
     for (int i = 0; i < np; ++i) {
       Ts0[i] = o->Ts[i] + t.dT_ocean[i]
@@ -620,3 +667,59 @@ void oracle_run(greb_oracle* o, int years, const float* co2_ppm, float* monthly,
   }
   o->it_scnr += (long)years * NT;
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * log_exp sensitivity experiments of the upstream model variant.
+ * All citations in this block are into /root/reference/src/greb.original.model.f90.
+ * ---------------------------------------------------------------------------------------- */
+/* greb_model preamble :162-197: boundary-data changes of the experiment, then the derived fields that are
+ * computed after them (cap_surf, initial q, wz_*).  z_ocean (:155-160) and Toclim (shell) keep their values
+ * from the unmodified data.  Call once, right after oracle_create. */
+void oracle_set_log_exp(greb_oracle* o, int log_exp) {
+  const size_t np = (size_t)o->np, n3 = np * NT;
+  o->log_exp = log_exp;
+  if (log_exp == 1) for (size_t i = 0; i < np; ++i) if (o->z_topo[i] > 1.f) o->z_topo[i] = 1.0f; /* :162 */
+  if (log_exp <= 2) for (size_t i = 0; i < n3; ++i) o->cldclim[i] = 0.7f;                          /* :163 */
+  if (log_exp <= 3) for (size_t i = 0; i < n3; ++i) o->qclim[i] = 0.0052f;                         /* :164 */
+  if (log_exp <= 9 || log_exp == 11) for (size_t i = 0; i < n3; ++i) o->mldclim[i] = o->p.d_ocean; /* :165-166 */
+  const size_t last = (size_t)(NT - 1) * np;
+  for (size_t i = 0; i < np; ++i) {
+    if (o->z_topo[i] > 0.f) o->cap_surf[i] = o->cap_land;                       /* :169 */
+    if (o->z_topo[i] <= 0.f) o->cap_surf[i] = o->cap_ocean * o->mldclim[i];     /* :170 */
+    o->q[i] = o->qclim[last + i];                                               /* :176 */
+    o->wz_air[i] = expf(-o->z_topo[i] / o->p.z_air);                            /* :182 */
+    o->wz_vapor[i] = expf(-o->z_topo[i] / o->p.z_vapor);                        /* :183 */
+  }
+}
+
+/* Start of the control / scenario loop of the original (:210-211, :219-220): clock, month counter and
+ * accumulators restart; the state is (re)set to state4 = Ts,Ta,To,q [4][np] if given.  cap_surf is NOT
+ * reset -- it carries over from the previous phase, as in the original. */
+void oracle_begin_run(greb_oracle* o, const float* state4, float year_start, int is_scenario) {
+  const size_t np = (size_t)o->np;
+  o->scenario = is_scenario;
+  o->mon = 1; o->it_scnr = 0; o->year = year_start;
+  memset(o->Tmm, 0, sizeof(float) * np); memset(o->Tamm, 0, sizeof(float) * np);
+  memset(o->Tomm, 0, sizeof(float) * np); memset(o->qmm, 0, sizeof(float) * np);
+  memset(o->apmm, 0, sizeof(float) * np);
+  if (state4) {
+    memcpy(o->Ts, state4, sizeof(float) * np); memcpy(o->Ta, state4 + np, sizeof(float) * np);
+    memcpy(o->To, state4 + 2 * np, sizeof(float) * np); memcpy(o->q, state4 + 3 * np, sizeof(float) * np);
+  }
+}
+
+/* co2_level :939-951 for the model year `year` */
+float oracle_co2_level(int log_exp, float year) {
+  float CO2 = 680.f;
+  if (log_exp == 12 || log_exp == 13) {
+    const float CO2_1950 = 310.f, CO2_2000 = 370.f, CO2_2050 = 520.f;
+    if (year <= 2000.f) CO2 = CO2_1950 + 60.f / 50.f * (year - 1950.f);
+    if (year > 2000.f && year <= 2050.f) CO2 = CO2_2000 + 150.f / 50.f * (year - 2000.f);
+    if (year > 2050.f && year <= 2100.f) CO2 = CO2_2050 + 180.f / 50.f * (year - 2050.f);
+  }
+  return CO2;
+}
+
+/* CO2_ctrl of the original (:178-179) is what qflux_correction runs at; src/greb.f90 calls it co2_flux */
+void oracle_set_co2_flux(greb_oracle* o, float co2) { o->p.co2_flux = co2; }

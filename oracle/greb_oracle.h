@@ -61,6 +61,16 @@ void oracle_flux_correction(greb_oracle* o, int years, float* yearly);
  * monthly [years][12][5][ny][nx]; yearly [years][2] or NULL */
 void oracle_run(greb_oracle* o, int years, const float* co2_ppm, float* monthly, float* yearly);
 
+/* ---- log_exp sensitivity experiments of the upstream model variant,
+ * /root/reference/src/greb.original.model.f90:60,162-166,394,423-430,452-453,492-495,513-515,553-571,939-951.
+ * Pinned against that program compiled in place (oracle/_ref/greb_orig) by tests/golden/make_golden.py.
+ * log_exp 10 (default) is the complete model == src/greb.f90.  Where the original reads an unassigned
+ * intent(out) circulation increment (log_exp <= 4; vapour at 7 and 16) the oracle defines it as 0. */
+void oracle_set_log_exp(greb_oracle* o, int log_exp);                   /* once, right after oracle_create */
+void oracle_begin_run(greb_oracle* o, const float* state4, float year_start, int is_scenario); /* control / scenario loop start */
+float oracle_co2_level(int log_exp, float year);
+void oracle_set_co2_flux(greb_oracle* o, float co2); /* CO2_ctrl, :178-179 */
+
 #ifdef __cplusplus
 }
 #endif

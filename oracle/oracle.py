@@ -23,6 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle_greb.so")
 REF_SO = os.path.join(HERE, "_ref", "libgreb_ref.so")
 REF_BIN = os.path.join(HERE, "_ref", "greb_ref")
+ORIG_BIN = os.path.join(HERE, "_ref", "greb_orig")  # the upstream variant with the log_exp switches
 NT = 730
 fp = abi.fptr
 
@@ -154,6 +155,41 @@ class Oracle:
 
     def state5(self):
         return np.stack([self.field(i).copy() for i in range(5)])
+
+    # ---- log_exp sensitivity experiments (greb.original.model.f90)
+    def set_log_exp(self, log_exp: int):
+        self.lib.oracle_set_log_exp(self.h, int(log_exp))
+
+    def begin_run(self, state4=None, year_start: float = 1940.0, scenario: bool = True):
+        s4 = None if state4 is None else np.ascontiguousarray(state4, np.float32)
+        self.lib.oracle_begin_run(self.h, None if s4 is None else fp(s4), C.c_float(year_start), int(scenario))
+
+    def co2_level(self, log_exp: int, year: float) -> float:
+        self.lib.oracle_co2_level.restype = C.c_float
+        return float(self.lib.oracle_co2_level(int(log_exp), C.c_float(year)))
+
+    def run_original(self, log_exp: int, time_flux: int, time_ctrl: int, time_scnr: int):
+        """greb_model of the original variant (greb.original.model.f90:139-233): flux correction at CO2_ctrl,
+        control run, scenario run -- both runs start from the state the flux-correction phase ended in (its
+        dummy arguments alias Ts_ini.., :201,:361) and carry cap_surf along.  Returns (control, scenario)
+        monthly means [years][12][5][ny][nx].  Call on a fresh Oracle."""
+        self.set_log_exp(log_exp)
+        co2_ctrl = 298.0 if log_exp in (12, 13) else 340.0  # :178-179
+        self.params.co2_flux = co2_ctrl
+        # the oracle keeps its own copy of the parameters: re-create semantics are not needed, co2_flux is
+        # read from that copy, so set it there through the field accessor below
+        self.lib.oracle_set_co2_flux(self.h, C.c_float(co2_ctrl))
+        self.flux_correction(time_flux)
+        start = np.stack([self.field(i).copy() for i in range(4)])
+        ctrl = None
+        if time_ctrl > 0:
+            self.begin_run(start, 1970.0, scenario=False)  # :210-211
+            ctrl, _ = self.run(time_ctrl, co2_ctrl)
+        self.begin_run(start, 1940.0, scenario=True)       # :219-220
+        years = np.float32(1940.0) + np.arange(time_scnr, dtype=np.float32)
+        co2 = [co2_ctrl if 14 <= log_exp <= 16 else self.co2_level(log_exp, float(y)) for y in years]  # :222-225
+        scen, _ = self.run(time_scnr, np.asarray(co2, np.float32))
+        return ctrl, scen
 
 
 # --------------------------------------------------------------------------------------------
@@ -315,3 +351,30 @@ def parse_ref_stdout(text: str) -> np.ndarray:
             except ValueError:
                 pass
     return np.asarray(rows, np.float64)
+
+
+def run_original_binary(inp: workload.Inputs, log_exp: int, time_flux: int, time_ctrl: int, time_scnr: int,
+                        workdir: str | None = None):
+    """Run oracle/_ref/greb_orig (the upstream variant, greb.original.shell.web-public.f90) in a scratch
+    directory: namelist_original + input/ in, output/control + output/scenario out.
+    Returns (control [months][5][ny][nx] or None, scenario [months][5][ny][nx], stdout)."""
+    if not os.path.exists(ORIG_BIN):
+        raise FileNotFoundError(ORIG_BIN + " (build with `make -C oracle ref` in the build container)")
+    wd = workdir or tempfile.mkdtemp(prefix="greb_orig_")
+    try:
+        inp.write_input_dir(os.path.join(wd, "input"))
+        os.makedirs(os.path.join(wd, "output"), exist_ok=True)
+        with open(os.path.join(wd, "namelist_original"), "w") as f:
+            f.write(f"&NUMERICS\ntime_flux = {time_flux}\ntime_ctrl = {time_ctrl}\ntime_scnr = {time_scnr}\n/\n"
+                    f"&PHYSICS\n log_exp = {log_exp}\n/\n")
+        r = subprocess.run([ORIG_BIN], cwd=wd, capture_output=True, text=True, check=True)
+        scen = workload.read_greb(os.path.join(wd, "output", "scenario"), inp.nx, inp.ny)
+        ctrl = None
+        if time_ctrl > 0:  # unit 21 first receives 730 TF_correct records (:204-206); the control run then
+            # overwrites records 1..60*time_ctrl; what is beyond stays TF_correct
+            raw = np.fromfile(os.path.join(wd, "output", "control"), dtype="<f4")
+            ctrl = raw[: time_ctrl * 60 * inp.nx * inp.ny].reshape(time_ctrl * 12, 5, inp.ny, inp.nx)
+        return ctrl, scen, r.stdout
+    finally:
+        if workdir is None:
+            shutil.rmtree(wd, ignore_errors=True)
