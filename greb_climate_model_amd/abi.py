@@ -11,6 +11,9 @@ NVAR_OUT = 5
 F_STRICT = 1
 F_MULTILAUNCH = 2
 RUN_DEVICE_OUT = 1
+# sensitivity-experiment switches, GREB_X_* of include/greb_engine.h
+X_NO_ICE, X_NO_HYDRO, X_NO_DEEP_OCEAN, X_LW_LINEAR_VAPOR = 1, 2, 4, 8
+X_NO_CIRCULATION, X_NO_VAPOR_TRANSPORT, X_VAPOR_DIFFUSION_ONLY, X_SST_PLUS1 = 16, 32, 64, 128
 
 c_float_p = C.POINTER(C.c_float)
 

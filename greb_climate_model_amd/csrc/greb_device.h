@@ -302,6 +302,10 @@ template <bool EXACT> __device__ __forceinline__ float flog(float x) { return EX
 template <bool EXACT> __device__ __forceinline__ float fexp(float x) { return EXACT ? expf(x) : __expf(x); }
 template <bool EXACT> __device__ __forceinline__ float fsqrt(float x) { return EXACT ? sqrtf(x) : __builtin_amdgcn_sqrtf(x); }
 
+// experiment switches: mirror of GREB_X_* (include/greb_engine.h; equality asserted in greb_engine.cpp)
+constexpr unsigned kXNoIce = 1u << 0, kXNoHydro = 1u << 1, kXNoDeepOcean = 1u << 2, kXLwLinear = 1u << 3,
+                   kXNoCirc = 1u << 4, kXNoQTransport = 1u << 5, kXQDiffOnly = 1u << 6, kXSstPlus1 = 1u << 7;
+
 struct Phys { // namelist physics_par + derived capacities, broadcast to the kernel
   float sig, ct_sens, da_ice, a_no_ice, a_cloud, Tl_ice1, Tl_ice2, To_ice1, To_ice2;
   float co_turb, ce, cq_latent, cq_rain, z_air, r_qviwv, rho_air;
@@ -318,7 +322,7 @@ __device__ __forceinline__ float pow4_ref(float x) {
 // a4 SWradiation :380-401 -> albedo, sw
 template <bool EXACT = true>
 __device__ __forceinline__ void sw_radiation(const Phys& P, float Ts, float z_topo, float glacier, float cld,
-                                             float sw_solar, float& albedo, float& sw) {
+                                             float sw_solar, float& albedo, float& sw, unsigned xsw = 0) {
 #pragma clang fp contract(off)
   const float a_atmos = cld * P.a_cloud;
   float a_surf = 0.f;
@@ -334,6 +338,7 @@ __device__ __forceinline__ void sw_radiation(const Phys& P, float Ts, float z_to
       a_surf = P.a_no_ice + P.da_ice * (1.f - fdiv<EXACT>(Ts - P.To_ice1, P.To_ice2 - P.To_ice1));
   }
   if (glacier > 0.5f) a_surf = P.a_no_ice + P.da_ice;
+  if (xsw & kXNoIce) a_surf = P.a_no_ice; // greb.original.model.f90:394
   albedo = a_surf + a_atmos - a_surf * a_atmos;
   sw = sw_solar * (1.f - albedo);
 }
@@ -342,14 +347,16 @@ __device__ __forceinline__ void sw_radiation(const Phys& P, float Ts, float z_to
 template <bool EXACT = true>
 __device__ __forceinline__ void lw_radiation(const Phys& P, float Ts, float Ta, float q, float co2, float ez,
                                              float cld, float tclim, float& LWsurf, float& LWair_down,
-                                             float& em) {
+                                             float& em, unsigned xsw = 0, float qclim = 0.f) {
 #pragma clang fp contract(off)
   const float e_co2 = ez * co2;
-  const float e_vapor = ez * P.r_qviwv * q;
+  float e_vapor = ez * P.r_qviwv * q;
+  if (xsw & kXLwLinear) e_vapor = ez * P.r_qviwv * qclim; // greb.original.model.f90:423
   float e = P.p_emi[3] * flog<EXACT>(P.p_emi[0] * e_co2 + P.p_emi[1] * e_vapor + P.p_emi[2]) + P.p_emi[6]
             + P.p_emi[4] * flog<EXACT>(P.p_emi[0] * e_co2 + P.p_emi[2])
             + P.p_emi[5] * flog<EXACT>(P.p_emi[1] * e_vapor + P.p_emi[2]);
   e = fdiv<EXACT>(P.p_emi[7] - cld, P.p_emi[8]) * (e - P.p_emi[9]) + P.p_emi[9];
+  if (xsw & kXLwLinear) e = e + 0.022f / (0.15f * 24.f) * P.r_qviwv * (q - qclim); // greb.original.model.f90:430
   em = e;
   LWsurf = -P.sig * pow4_ref(Ts);
   const float dTrad = -0.16f * tclim - 5.f;
@@ -360,8 +367,9 @@ __device__ __forceinline__ void lw_radiation(const Phys& P, float Ts, float Ta, 
 template <bool EXACT = true>
 __device__ __forceinline__ void hydro(const Phys& P, float Ts, float q, float u, float v, float z_topo,
                                       float ez, float swet, float& Qlat, float& Qlat_air, float& dq_eva,
-                                      float& dq_rain) {
+                                      float& dq_rain, unsigned xsw = 0) {
 #pragma clang fp contract(off)
+  if (xsw & kXNoHydro) { Qlat = Qlat_air = dq_eva = dq_rain = 0.f; return; } // greb.original.model.f90:452-453
   float abswind = fsqrt<EXACT>(u * u + v * v);
   if (z_topo > 0.f) abswind = fsqrt<EXACT>(abswind * abswind + 2.0f * 2.0f);
   if (z_topo < 0.f) abswind = fsqrt<EXACT>(abswind * abswind + 3.0f * 3.0f);
@@ -376,8 +384,10 @@ __device__ __forceinline__ void hydro(const Phys& P, float Ts, float q, float u,
 // a7 deep_ocean :505-523
 template <bool EXACT = true>
 __device__ __forceinline__ void deep_ocean(const Phys& P, float Ts, float To, float z_topo, float mld,
-                                           float mld_prev, float z_ocean, float& dT_ocean, float& dTo) {
+                                           float mld_prev, float z_ocean, float& dT_ocean, float& dTo,
+                                           unsigned xsw = 0) {
 #pragma clang fp contract(off)
+  if (xsw & kXNoDeepOcean) { dT_ocean = dTo = 0.f; return; } // greb.original.model.f90:513-515
   float a = 0.f, b = 0.f;
   const float dmld = mld - mld_prev;
   if (z_topo < 0.f && Ts >= P.To_ice2 && dmld < 0.f) a = fdiv<EXACT>(-dmld, z_ocean - mld) * (Ts - To);
@@ -392,13 +402,17 @@ __device__ __forceinline__ void deep_ocean(const Phys& P, float Ts, float To, fl
 // a8 seaice :483-490 -> new cap_surf
 template <bool EXACT = true>
 __device__ __forceinline__ float seaice(const Phys& P, float Ts, float z_topo, float glacier, float mld,
-                                        float cap_surf) {
+                                        float cap_surf, unsigned xsw = 0) {
 #pragma clang fp contract(off)
   if (z_topo < 0.f) {
     if (Ts <= P.To_ice1) cap_surf = P.cap_land;
     if (Ts >= P.To_ice2) cap_surf = P.cap_ocean * mld;
     if (Ts > P.To_ice1 && Ts < P.To_ice2)
       cap_surf = P.cap_land + fdiv<EXACT>(P.cap_ocean * mld - P.cap_land, P.To_ice2 - P.To_ice1) * (Ts - P.To_ice1);
+  }
+  if (xsw & kXNoIce) { // greb.original.model.f90:492-495
+    if (z_topo > 0.f) cap_surf = P.cap_land;
+    if (z_topo < 0.f) cap_surf = P.cap_ocean * mld;
   }
   if (glacier > 0.5f) cap_surf = P.cap_land;
   return cap_surf;

@@ -102,6 +102,7 @@ struct greb_engine {
   greb_params p{};
   int nx = 0, ny = 0, np = 0, nm = 0, device = 0;
   bool strict = false;
+  unsigned xsw = 0; // sensitivity-experiment switches (GREB_X_*)
   bool shared_corr = true; // all members share physics -> one flux-correction set
   bool fused = true;       // every member has the 96x48 default sub-cycling layout -> fused member kernel
   float *Xa = nullptr, *Xb = nullptr, *red = nullptr, *W2 = nullptr; // any-grid (multi-launch) engine work arrays
@@ -152,6 +153,8 @@ MemberArgs base_args(greb_engine* e) {
   if (const char* ns = getenv("GREB_DEBUG_NSUB")) a.nsub = atoi(ns); // timing experiments only
   a.co2_flux = e->p.co2_flux;
   a.ipx = e->p.ipx; a.ipy = e->p.ipy;
+  a.xsw = e->xsw;
+  if (e->xsw & GREB_X_NO_CIRCULATION) a.nsub = 0; // no transport at all: the tracers come back unchanged
   return a;
 }
 
@@ -181,7 +184,7 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     float *cur = e->Xa, *nxt = e->Xb;
     for (int tt = 0; tt < a.nsub; ++tt) {
       HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
-                                      e->ny, nrun, e->strict, e->stream));
+                                      e->ny, nrun, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
       float* t = cur; cur = nxt; nxt = t;
     }
     MemberArgs b = a;
@@ -459,6 +462,31 @@ int greb_engine_get_corrections(greb_engine* e, int member, float* corr, float* 
   return 0;
 }
 
+static_assert(GREB_X_NO_ICE == kXNoIce && GREB_X_NO_HYDRO == kXNoHydro && GREB_X_NO_DEEP_OCEAN == kXNoDeepOcean &&
+              GREB_X_LW_LINEAR_VAPOR == kXLwLinear && GREB_X_NO_CIRCULATION == kXNoCirc &&
+              GREB_X_NO_VAPOR_TRANSPORT == kXNoQTransport && GREB_X_VAPOR_DIFFUSION_ONLY == kXQDiffOnly &&
+              GREB_X_SST_PLUS1 == kXSstPlus1, "device switch constants mirror the ABI");
+
+// greb.original.model.f90: which process each log_exp value switches off (the conditions are the original's)
+unsigned greb_log_exp_switches(int le) {
+  unsigned x = 0;
+  if (le <= 5) x |= GREB_X_NO_ICE;                                        // :394, :492
+  if (le <= 6 || le == 13 || le == 15) x |= GREB_X_NO_HYDRO;              // :453
+  if (le <= 9 || le == 11 || (le >= 14 && le <= 16)) x |= GREB_X_NO_DEEP_OCEAN; // :514-515
+  if (le == 11) x |= GREB_X_LW_LINEAR_VAPOR;                              // :423, :430
+  if (le <= 4) x |= GREB_X_NO_CIRCULATION;                                // :553
+  if (le == 7 || le == 16) x |= GREB_X_NO_VAPOR_TRANSPORT;                // :554-555
+  if (le == 8) x |= GREB_X_VAPOR_DIFFUSION_ONLY;                          // :560
+  if (le >= 14 && le <= 16) x |= GREB_X_SST_PLUS1;                        // :226
+  return x;
+}
+
+int greb_engine_set_experiment(greb_engine* e, unsigned switches) {
+  if (!e || (switches & ~0xffu)) return fail(e, GREB_E_INVALID, "set_experiment: unknown switch bits");
+  e->xsw = switches;
+  return 0;
+}
+
 int greb_engine_set_corrections(greb_engine* e, int member, const float* corr, const float* state5) {
   if (!e || member < -1 || member >= e->nm) return fail(e, GREB_E_INVALID, "set_corrections: bad argument");
   HIP_TRY(e, hipSetDevice(e->device));
@@ -572,6 +600,7 @@ int greb_engine_point_physics(greb_engine* e, int ityr, float co2, const float* 
   a.z_topo = e->z_topo; a.glacier = e->glacier; a.sw_solar = e->sw_solar; a.tclim = e->tclim;
   a.uclim = e->uclim; a.vclim = e->vclim; a.mldclim = e->mldclim; a.cldclim = e->cldclim; a.swetclim = e->swetclim;
   a.z_ocean = e->z_ocean; a.wz_air = e->wz_air; a.phys = e->h_phys[0]; a.in5 = in.p; a.out15 = out.p;
+  a.xsw = e->xsw; a.qclim = e->qclim;
   HIP_TRY(e, launch_point_physics(a, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   HIP_TRY(e, hipMemcpy(out15, out.p, 15 * np * 4, hipMemcpyDeviceToHost));

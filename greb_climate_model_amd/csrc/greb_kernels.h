@@ -39,6 +39,7 @@ struct MemberArgs {
   float* yearly;         // [nm][yearly_years][2] or nullptr
   int yearly_years, yearly_year0;
   int ipx, ipy;          // 1-based
+  unsigned xsw;          // experiment switches (kX*, greb_device.h); 0 = complete model
 };
 
 // fused engine (greb_member.hip): 96x48 with the default sub-cycling layout -- rows 0-9 and 38-47
@@ -61,7 +62,7 @@ hipError_t launch_circulation(const float* X, const float* wz, const float* u, c
 // any-grid multi-launch engine (greb_kernels.hip)
 hipError_t launch_substep_fused(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
                                 const RowTables* tabs, const int* tab_index, int nx, int ny, int n_members,
-                                bool strict, hipStream_t s);
+                                bool strict, hipStream_t s, bool calm_vapor = false);
 hipError_t launch_physics_step(const MemberArgs& a, const float* X, float* Xout, float* red, int n_members,
                                bool strict, hipStream_t s);
 hipError_t launch_yearly(const float* red, float* yearly, int np, int nx, int ipx, int ipy, int yearly_years,
@@ -74,6 +75,8 @@ struct PointArgs {
   const float *z_topo, *glacier, *sw_solar, *tclim, *uclim, *vclim, *mldclim, *cldclim, *swetclim;
   const float *z_ocean, *wz_air;
   Phys phys;
+  unsigned xsw;       // experiment switches
+  const float* qclim; // for kXLwLinear
   const float* in5; // Ts, Ta, To, q, cap_surf
   float* out15;
 };

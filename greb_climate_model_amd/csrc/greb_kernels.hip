@@ -23,9 +23,11 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
                                                     const float* __restrict__ ug, const float* __restrict__ vg,
                                                     float* __restrict__ dX, const RowTables* __restrict__ tabp,
                                                     int nx, int ny, int rows_per_band, int wmod, int uv_shared,
-                                                    const int* __restrict__ tab_index, int tab_div) {
+                                                    const int* __restrict__ tab_index, int tab_div, int calm_odd) {
   // batch item b: field T1[b]; weights wz[b % wmod] (wmod = 0: wz[b]); winds u,v[b] or shared;
-  // row tables tabp[tab_index[b / tab_div]] (tab_index = nullptr: tabp[0])
+  // row tables tabp[tab_index[b / tab_div]] (tab_index = nullptr: tabp[0]);
+  // calm_odd: odd batch items (the vapour fields of the engine) see zero wind -- the experiment that diffuses
+  // but does not advect q (greb.original.model.f90:560-564): every advective increment is then exactly 0
   extern __shared__ __align__(16) float lds_raw[];
   lfloat* lds = (lfloat*)lds_raw;
   const int b = blockIdx.x;
@@ -53,8 +55,9 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
   }
   if (kWinds)
     for (int i = threadIdx.x; i < (k1 - k0) * nq; i += blockDim.x) {
-      st4(sU + 4 * i, ld4(ug + fu + (size_t)k0 * nx + 4 * i));
-      st4(sV + 4 * i, ld4(vg + fu + (size_t)k0 * nx + 4 * i));
+      const bool calm = calm_odd && (b & 1);
+      st4(sU + 4 * i, calm ? zero4() : ld4(ug + fu + (size_t)k0 * nx + 4 * i));
+      st4(sV + 4 * i, calm ? zero4() : ld4(vg + fu + (size_t)k0 * nx + 4 * i));
     }
   __syncthreads();
   const Rows X{sT, r0, nx}, W{sW, r0, nx}, U{sU, k0, nx}, V{sV, k0, nx};
@@ -237,7 +240,8 @@ static int pick_band_rows(int nx, int ny, int halo, int extra_fields) {
 template <int MODE>
 static hipError_t launch_sweep(const float* T1, const float* wz, const float* u, const float* v, float* dX,
                                const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s,
-                               int wmod = 0, int uv_shared = 0, const int* tab_index = nullptr, int tab_div = 1) {
+                               int wmod = 0, int uv_shared = 0, const int* tab_index = nullptr, int tab_div = 1,
+                               int calm_odd = 0) {
   constexpr int halo = MODE == kChainDif ? 1 : 2;
   constexpr int extra = MODE == kChainDif ? 0 : 2;
   const int rows = pick_band_rows(nx, ny, halo, extra);
@@ -248,7 +252,7 @@ static hipError_t launch_sweep(const float* T1, const float* wz, const float* u,
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, block, lds, s, T1, wz, u, v, dX, tab_dev, nx, ny, rows, wmod, uv_shared, tab_index, tab_div);
+  hipLaunchKernelGGL(kern, grid, block, lds, s, T1, wz, u, v, dX, tab_dev, nx, ny, rows, wmod, uv_shared, tab_index, tab_div, calm_odd);
   return hipGetLastError();
 }
 
@@ -317,16 +321,16 @@ __global__ void point_kernel(PointArgs a) {
   const float zt = a.z_topo[p], gl = a.glacier[p], ez = a.wz_air[p];
   const float cld = a.cldclim[off + p], mld = a.mldclim[off + p];
   float albedo, sw, LWsurf, LWdown, em, Qlat, Qlat_air, dq_eva, dq_rain, dT_ocean, dTo;
-  sw_radiation(a.phys, Ts, zt, gl, cld, a.sw_solar[(size_t)(a.ityr - 1) * a.ny + p / a.nx], albedo, sw);
-  lw_radiation(a.phys, Ts, Ta, q, a.co2, ez, cld, a.tclim[off + p], LWsurf, LWdown, em);
-  hydro(a.phys, Ts, q, a.uclim[off + p], a.vclim[off + p], zt, ez, a.swetclim[off + p], Qlat, Qlat_air, dq_eva, dq_rain);
-  deep_ocean(a.phys, Ts, To, zt, mld, a.mldclim[offm + p], a.z_ocean[p], dT_ocean, dTo);
+  sw_radiation(a.phys, Ts, zt, gl, cld, a.sw_solar[(size_t)(a.ityr - 1) * a.ny + p / a.nx], albedo, sw, a.xsw);
+  lw_radiation(a.phys, Ts, Ta, q, a.co2, ez, cld, a.tclim[off + p], LWsurf, LWdown, em, a.xsw, a.qclim[off + p]);
+  hydro(a.phys, Ts, q, a.uclim[off + p], a.vclim[off + p], zt, ez, a.swetclim[off + p], Qlat, Qlat_air, dq_eva, dq_rain, a.xsw);
+  deep_ocean(a.phys, Ts, To, zt, mld, a.mldclim[offm + p], a.z_ocean[p], dT_ocean, dTo, a.xsw);
   float Qsens;
   {
 #pragma clang fp contract(off)
     Qsens = a.phys.ct_sens * (Ta - Ts); // :295
   }
-  const float capn = seaice(a.phys, Ts, zt, gl, mld, cap);
+  const float capn = seaice(a.phys, Ts, zt, gl, mld, cap, a.xsw);
   const float o[15] = {albedo, sw, LWsurf, LWdown, em, Qsens, Qlat, Qlat_air, dq_eva, dq_rain, dT_ocean, dTo, capn, 0.f, 0.f};
   for (int i = 0; i < 15; ++i) a.out15[(size_t)i * a.np + p] = o[i];
 }
@@ -344,12 +348,12 @@ hipError_t launch_point_physics(const PointArgs& a, hipStream_t s) {
 // ============================================================================================
 hipError_t launch_substep_fused(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
                                 const RowTables* tabs, const int* tab_index, int nx, int ny, int n_members,
-                                bool strict, hipStream_t s) {
+                                bool strict, hipStream_t s, bool calm_vapor) {
   // batch = n_members x {Tair, q}; weights W2[2] = {wz_air, wz_vapor}; winds shared by everyone
-  return launch_sweep<kChainFused>(X, W2, u, v, Xnew, tabs, nx, ny, 2 * n_members, strict, s, 2, 1, tab_index, 2);
+  return launch_sweep<kChainFused>(X, W2, u, v, Xnew, tabs, nx, ny, 2 * n_members, strict, s, 2, 1, tab_index, 2, calm_vapor ? 1 : 0);
 }
 
-template <bool STRICT, bool FLUX>
+template <bool STRICT, bool FLUX, bool EXP>
 __global__ __launch_bounds__(256) void physics_step_kernel(MemberArgs a, const float* __restrict__ X,
                                                            float* __restrict__ Xout, float* __restrict__ red) {
   const int m = blockIdx.y, np = a.np;
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void physics_step_kernel(MemberArgs a, const f
   float* corr = a.corr + (size_t)a.corr_index[m] * 3 * kNT * np;
   const f4 xTa = ld4(X + ((size_t)m * 2) * np + 4 * qd), xq = ld4(X + ((size_t)m * 2 + 1) * np + 4 * qd);
   f4 oTa, oq, tsm;
-  physics_quad<STRICT, FLUX>(a, P, m, qd, ck, co2, state, acc, corr, xTa, xq, oTa, oq, tsm);
+  physics_quad<STRICT, FLUX, EXP>(a, P, m, qd, ck, co2, state, acc, corr, xTa, xq, oTa, oq, tsm);
   st4(Xout + ((size_t)m * 2) * np + 4 * qd, oTa);
   st4(Xout + ((size_t)m * 2 + 1) * np + 4 * qd, oq);
   if (ck.ityr == kNT) st4(red + (size_t)m * np + 4 * qd, tsm);
@@ -372,8 +376,11 @@ __global__ __launch_bounds__(256) void physics_step_kernel(MemberArgs a, const f
 hipError_t launch_physics_step(const MemberArgs& a, const float* X, float* Xout, float* red, int n_members,
                                bool strict, hipStream_t s) {
   void (*kern)(MemberArgs, const float*, float*, float*);
-  if (a.flux_phase) kern = strict ? physics_step_kernel<true, true> : physics_step_kernel<false, true>;
-  else kern = strict ? physics_step_kernel<true, false> : physics_step_kernel<false, false>;
+  if (a.xsw) {
+    if (a.flux_phase) kern = strict ? physics_step_kernel<true, true, true> : physics_step_kernel<false, true, true>;
+    else kern = strict ? physics_step_kernel<true, false, true> : physics_step_kernel<false, false, true>;
+  } else if (a.flux_phase) kern = strict ? physics_step_kernel<true, true, false> : physics_step_kernel<false, true, false>;
+  else kern = strict ? physics_step_kernel<true, false, false> : physics_step_kernel<false, false, false>;
   hipLaunchKernelGGL(kern, dim3((a.np / 4 + 255) / 256, n_members), dim3(256), 0, s, a, X, Xout, red);
   return hipGetLastError();
 }

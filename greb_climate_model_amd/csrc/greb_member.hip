@@ -77,7 +77,7 @@ __device__ __forceinline__ q8 zip(const f4& a, const f4& b) {
 // one bulk task: pair-quad (k, q) -> X_new = (X + dX_diffuse) + dX_advec, both tracers
 // ---------------------------------------------------------------------------------------------
 template <bool STRICT, bool SUB>
-__device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q) {
+__device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q, bool calm_q = false) {
   const int qm = q == 0 ? NQ - 1 : q - 1, qp = q == NQ - 1 ? 0 : q + 1;
   const lfloat* Xc = lds + kOffX + cur * 2 * NP;
   const lfloat* Wc = lds + kOffW;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q) {
 #pragma clang fp contract(off)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float x = in.T[4 + i] + dd[i] + da[i]; // :549
+          const float x = (calm_q && tr == 1) ? in.T[4 + i] + dd[i] : in.T[4 + i] + dd[i] + da[i]; // :549 (orig :562)
           if (tr == 0) xn.v[i].x = x; else xn.v[i].y = x;
         }
       }
@@ -138,7 +138,7 @@ __device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q) {
       vm[i] = fm * fmaxf(yq.v[i], 0.f); vp[i] = fp * fminf(yq.v[i], 0.f);
     }
     xn = substep_pair<SUB>(T, w, Tm2, Tm1, Tp1, Tp2, Wm2, Wm1, Wp1, Wp2, um, up, vm, vp, rk.dif_cc * 0.05f,
-                           rk.dif_ccy, q == NQ - 1);
+                           rk.dif_ccy, q == NQ - 1, calm_q);
   }
   st8(lds + kOffX + (cur ^ 1) * 2 * NP + k * RS, q, xn);
 }
@@ -159,16 +159,16 @@ __device__ __forceinline__ int pass_of(int wave, int i) {
 }
 
 template <bool STRICT>
-__device__ __forceinline__ void bulk_substep(lfloat* lds, int cur, int wave, int lane, int dbg) {
+__device__ __forceinline__ void bulk_substep(lfloat* lds, int cur, int wave, int lane, int dbg, bool calm_q = false) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int pass = __builtin_amdgcn_readfirstlane(pass_of(wave, i));
     if (pass < 7) {
       const int t = pass * 64 + lane;
-      if (t < kSubTasks && !(dbg & 1)) row_task<STRICT, true>(lds, cur, sub_row(t / NQ), t % NQ);
+      if (t < kSubTasks && !(dbg & 1)) row_task<STRICT, true>(lds, cur, sub_row(t / NQ), t % NQ, calm_q);
     } else {
       const int t = (pass - 7) * 64 + lane;
-      if (t < kFullTasks && !(dbg & 2)) row_task<STRICT, false>(lds, cur, 10 + t / NQ, t % NQ);
+      if (t < kFullTasks && !(dbg & 2)) row_task<STRICT, false>(lds, cur, 10 + t / NQ, t % NQ, calm_q);
     }
   }
 }
@@ -194,7 +194,7 @@ __device__ __forceinline__ void st_pair2(lfloat* p, v2 a, v2 b) {
 }
 
 template <bool STRICT>
-__device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole) {
+__device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, bool calm_q = false) {
   const int l = threadIdx.x & 63;
   if (l >= 48) return; // idle lanes (no workgroup barrier inside this function)
   const int k = pole ? NY - 1 : 0;
@@ -319,7 +319,7 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole) {
         const float th0 = tr ? Th[0][pt].y : Th[0][pt].x, th1 = tr ? Th[1][pt].y : Th[1][pt].x;
         const float dd = w0 * ((th0 - t0) + dTy); // :718, :721
         const float da = (th1 - t0) + aTy;        // :910, :913
-        const float x = t0 + dd + da;             // :549
+        const float x = (calm_q && tr == 1) ? t0 + dd : t0 + dd + da; // :549 (orig :562)
         if (tr) xn[pt].y = x; else xn[pt].x = x;
       }
     } else {
@@ -331,7 +331,8 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole) {
       const v2 ddy = rk.dif_ccy * g1;
       const v2 day = cv * (d2 - g1);
       const v2 dd = w[4 + pt] * ((Th[0][pt] - own[pt]) + ddy);
-      const v2 da = (Th[1][pt] - own[pt]) + day;
+      v2 da = (Th[1][pt] - own[pt]) + day;
+      if (calm_q) da.y = 0.f;
       xn[pt] = (own[pt] + dd) + da;
     }
   }
@@ -368,10 +369,10 @@ struct Circ {
   }
 
   // dbg: timing experiments only (tools/microbench_circ.py): bit0/1/2 skip sub / full / chain work
-  __device__ __forceinline__ void substep(lfloat* lds, int cur, int dbg = 0) {
+  __device__ __forceinline__ void substep(lfloat* lds, int cur, int dbg = 0, bool calm_q = false) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave < 6) bulk_substep<STRICT>(lds, cur, wave, lane, dbg);
-    else if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, wave - 6);
+    if (wave < 6) bulk_substep<STRICT>(lds, cur, wave, lane, dbg, calm_q);
+    else if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, wave - 6, calm_q);
   }
 };
 
@@ -425,7 +426,8 @@ hipError_t launch_circulation_g96(const float* X, const float* wz, const float* 
 // ---------------------------------------------------------------------------------------------
 // the member kernel
 // ---------------------------------------------------------------------------------------------
-template <bool STRICT, bool FLUX>
+// EXP: honour the sensitivity-experiment switches a.xsw; the default instantiation has none of it
+template <bool STRICT, bool FLUX, bool EXP>
 __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
   extern __shared__ __align__(16) float lds_raw[];
   lfloat* lds = (lfloat*)lds_raw;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     // ---- circulation of Tair and q: 24 sub-steps (:543-550)
 #pragma unroll 1
     for (int tt = 0; tt < a.nsub; ++tt) {
-      circ.substep(lds, cur);
+      circ.substep(lds, cur, 0, EXP && (a.xsw & kXQDiffOnly));
       __syncthreads();
       cur ^= 1;
     }
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     for (int qd = tid; qd < NP / 4; qd += kThreads) {
       const q8 xpair = ld8(Xf + (qd / NQ) * RS, qd % NQ);
       f4 oTa, oq, tsm;
-      physics_quad<STRICT, FLUX>(a, P, m, qd, ck, co2, state, acc, corr, comp(xpair, 0), comp(xpair, 1), oTa, oq, tsm);
+      physics_quad<STRICT, FLUX, EXP>(a, P, m, qd, ck, co2, state, acc, corr, comp(xpair, 0), comp(xpair, 1), oTa, oq, tsm);
       st8(Xf + (qd / NQ) * RS, qd % NQ, zip(oTa, oq));
       if (ityr == kNT) st4(red + 4 * qd, tsm);
     }
@@ -495,8 +497,11 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
 hipError_t launch_member_kernel(const MemberArgs& a, int n_members, bool strict, hipStream_t s) {
   if (a.nx != NX || a.ny != NY) return hipErrorInvalidValue;
   void (*kern)(MemberArgs);
-  if (a.flux_phase) kern = strict ? member_kernel<true, true> : member_kernel<false, true>;
-  else kern = strict ? member_kernel<true, false> : member_kernel<false, false>;
+  if (a.xsw) { // sensitivity experiment: the switch-aware instantiation
+    if (a.flux_phase) kern = strict ? member_kernel<true, true, true> : member_kernel<false, true, true>;
+    else kern = strict ? member_kernel<true, false, true> : member_kernel<false, false, true>;
+  } else if (a.flux_phase) kern = strict ? member_kernel<true, true, false> : member_kernel<false, true, false>;
+  else kern = strict ? member_kernel<true, false, false> : member_kernel<false, false, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
   if (e != hipSuccess) return e;

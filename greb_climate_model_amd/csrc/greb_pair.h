@@ -127,7 +127,7 @@ __device__ __forceinline__ q8 substep_pair(const v2 T[12], const v2 w[12], const
                                            const q8& Tp1, const q8& Tp2, const q8& wm2, const q8& wm1,
                                            const q8& wp1, const q8& wp2, const float um[4], const float up[4],
                                            const float vm[4], const float vp[4], float cs_dif, float ccy_dif,
-                                           bool last_quad) {
+                                           bool last_quad, bool calm_q = false) {
   Flux2 f;
   make_flux2(T, w, f);
   v2 ddx[4], dax[4], ddy[4], day[4];
@@ -148,7 +148,8 @@ __device__ __forceinline__ q8 substep_pair(const v2 T[12], const v2 w[12], const
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const v2 dd = w[4 + i] * (ddx[i] + ddy[i]); // :721
-    const v2 da = dax[i] + day[i];              // :913
+    v2 da = dax[i] + day[i];                    // :913
+    if (calm_q) da.y = 0.f; // experiment: vapour is diffused but not advected (greb.original.model.f90:560-564)
     r.v[i] = (T[4 + i] + dd) + da;              // :549
   }
   return r;

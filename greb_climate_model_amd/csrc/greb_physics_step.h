@@ -31,7 +31,8 @@ __device__ __forceinline__ StepClock step_clock(const MemberArgs& a, long long i
 
 // state/acc/corr: this member's arrays.  Returns the annual-mean Tsurf quad in tsmn_mean when
 // ityr == 730 (the caller feeds the sequential global-mean sum, :954).
-template <bool STRICT, bool FLUX>
+// EXP: the sensitivity-experiment switches a.xsw are honoured; false compiles them out.
+template <bool STRICT, bool FLUX, bool EXP = false>
 __device__ __forceinline__ void physics_quad(const MemberArgs& a, const Phys& P, int m, int qd, const StepClock& ck,
                                              float co2, float* __restrict__ state, float* __restrict__ acc,
                                              float* __restrict__ corr, const f4& xTa, const f4& xq, f4& oTa_out,
@@ -39,6 +40,7 @@ __device__ __forceinline__ void physics_quad(const MemberArgs& a, const Phys& P,
   const int nx = a.nx, ny = a.ny, np = a.np;
   const int ityr = ck.ityr, mon = ck.mon, yr_rel = ck.yr_rel;
   const size_t off = ck.off, offm = ck.offm;
+  const unsigned xsw = EXP ? a.xsw : 0u;
     const int p0 = 4 * qd;
     const f4 vTs = ld4(state + p0), vTa = ld4(state + np + p0), vTo = ld4(state + 2 * np + p0),
              vq = ld4(state + 3 * np + p0), vcap = ld4(state + 4 * np + p0);
@@ -53,20 +55,25 @@ __device__ __forceinline__ void physics_quad(const MemberArgs& a, const Phys& P,
     f4 acc0, acc1, acc2, acc3, acc4;
     const f4 acc5 = ld4(acc + 5 * np + p0);
     if (!FLUX) { acc0 = ld4(acc + p0); acc1 = ld4(acc + np + p0); acc2 = ld4(acc + 2 * np + p0); acc3 = ld4(acc + 3 * np + p0); acc4 = ld4(acc + 4 * np + p0); }
+    f4 vqcl = zero4(), vtclp = zero4(); // experiments only: qclim(ityr) for the linear emissivity, Tclim of the previous step
+    if (EXP && (xsw & kXLwLinear)) vqcl = FLUX ? vc1 : ld4(a.qclim + off + p0);
+    if (EXP && !FLUX && (xsw & kXSstPlus1)) vtclp = ld4(a.tclim + offm + p0);
     f4 oTs, oTa, oTo, oq, ocap, oTF, oqF, oToF, oalb, otsmn;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma clang fp contract(off)
-      const float Ts1 = vTs.v[e], Ta1 = vTa.v[e], To1 = vTo.v[e], q1 = vq.v[e], cap = vcap.v[e];
+      float Ts1 = vTs.v[e];
+      const float Ta1 = vTa.v[e], To1 = vTo.v[e], q1 = vq.v[e], cap = vcap.v[e];
       const float zt = vzt.v[e], gl = vgl.v[e], ez = vez.v[e], tcl = vtcl.v[e], cld = vcld.v[e], mld = vmld.v[e];
+      if (EXP && !FLUX && (xsw & kXSstPlus1) && zt < 0.0f) Ts1 = vtclp.v[e] + 1.0f; // greb.original.model.f90:226
       const float dTa_crcl = xTa.v[e] - Ta1; // :551
-      const float dq_crcl = xq.v[e] - q1;
+      const float dq_crcl = (EXP && (xsw & kXNoQTransport)) ? 0.f : xq.v[e] - q1; // greb.original.model.f90:554-555
       float albedo, sw, LWsurf, LWdown, em, Qlat, Qlat_air, dq_eva, dq_rain, dT_ocean, dTo;
-      sw_radiation<STRICT>(P, Ts1, zt, gl, cld, solar, albedo, sw);
-      lw_radiation<STRICT>(P, Ts1, Ta1, q1, co2, ez, cld, tcl, LWsurf, LWdown, em);
+      sw_radiation<STRICT>(P, Ts1, zt, gl, cld, solar, albedo, sw, xsw);
+      lw_radiation<STRICT>(P, Ts1, Ta1, q1, co2, ez, cld, tcl, LWsurf, LWdown, em, xsw, vqcl.v[e]);
       const float Qsens = P.ct_sens * (Ta1 - Ts1); // :295
-      hydro<STRICT>(P, Ts1, q1, vu.v[e], vv.v[e], zt, ez, vswet.v[e], Qlat, Qlat_air, dq_eva, dq_rain);
-      deep_ocean<STRICT>(P, Ts1, To1, zt, mld, vmldm.v[e], vzo.v[e], dT_ocean, dTo);
+      hydro<STRICT>(P, Ts1, q1, vu.v[e], vv.v[e], zt, ez, vswet.v[e], Qlat, Qlat_air, dq_eva, dq_rain, xsw);
+      deep_ocean<STRICT>(P, Ts1, To1, zt, mld, vmldm.v[e], vzo.v[e], dT_ocean, dTo, xsw);
       const float LWup = LWdown; // :432
       float Ts0, Ta0, To0, q0;
       if (FLUX) {
@@ -94,7 +101,7 @@ __device__ __forceinline__ void physics_quad(const MemberArgs& a, const Phys& P,
         q0 = q1 + dq;                                                                            // :266
       }
       oTs.v[e] = Ts0; oTa.v[e] = Ta0; oTo.v[e] = To0; oq.v[e] = q0;
-      ocap.v[e] = seaice<STRICT>(P, Ts0, zt, gl, mld, cap);                                              // :268/:357
+      ocap.v[e] = seaice<STRICT>(P, Ts0, zt, gl, mld, cap, xsw);                                              // :268/:357
       oalb.v[e] = albedo;
       otsmn.v[e] = acc5.v[e] + Ts0;                                                              // :945
     }

@@ -41,7 +41,7 @@ EXPORTS = ["greb_params_default", "greb_engine_create", "greb_engine_flux_correc
            "greb_engine_get_corrections", "greb_engine_set_corrections", "greb_engine_get_state",
            "greb_engine_last_error", "greb_engine_destroy", "greb_device_info", "greb_diffusion_batched",
            "greb_advection_batched", "greb_circulation_batched", "greb_diffusion_batched_dev",
-           "greb_engine_point_physics"]
+           "greb_engine_point_physics", "greb_log_exp_switches", "greb_engine_set_experiment"]
 
 
 def _check(rc: int, h=None):
@@ -52,6 +52,13 @@ def _check(rc: int, h=None):
 
 def device_info(device: int = 0) -> dict:
     return json.loads(lib().greb_device_info(device).decode())
+
+
+def log_exp_switches(log_exp: int) -> int:
+    """Process switches of the upstream variant's experiment number (greb.original.model.f90:60)."""
+    f = lib().greb_log_exp_switches
+    f.restype = C.c_uint
+    return int(f(int(log_exp)))
 
 
 def params_default() -> abi.GrebParams:
@@ -127,9 +134,15 @@ class Engine:
         return corr, st
 
     def set_corrections(self, corr, state5, member: int = -1):
-        corr = np.ascontiguousarray(corr, np.float32)
-        state5 = np.ascontiguousarray(state5, np.float32)
-        _check(lib().greb_engine_set_corrections(self.h, member, abi.fptr(corr), abi.fptr(state5)), self.h)
+        """Either argument may be None (left unchanged); member -1 = every member."""
+        corr = None if corr is None else np.ascontiguousarray(corr, np.float32)
+        state5 = None if state5 is None else np.ascontiguousarray(state5, np.float32)
+        _check(lib().greb_engine_set_corrections(self.h, member, None if corr is None else abi.fptr(corr),
+                                                 None if state5 is None else abi.fptr(state5)), self.h)
+
+    def set_experiment(self, switches: int):
+        """Sensitivity-experiment switches (abi.X_*; log_exp_switches() maps the original's log_exp)."""
+        _check(lib().greb_engine_set_experiment(self.h, C.c_uint(int(switches))), self.h)
 
     def point_physics(self, ityr: int, co2: float, in5) -> np.ndarray:
         in5 = np.ascontiguousarray(in5, np.float32)

@@ -109,6 +109,29 @@ int greb_engine_flux_correction(greb_engine* e, int years, float* yearly);
 int greb_engine_run(greb_engine* e, int years, const float* co2_ppm, float* monthly, float* yearly,
                     unsigned run_flags);
 
+/* ---- sensitivity-experiment switches -----------------------------------------
+ * Runtime switches on the same kernels that reproduce the `log_exp` experiments of the upstream model
+ * variant (src/greb.original.model.f90:60,162-166,394,423-430,452-453,492-495,513-515,553-571; doc in its
+ * namelist_original).  greb_log_exp_switches() maps a log_exp value to the process switches below; the
+ * experiment's changes to the BOUNDARY DATA (constant topography / clouds / vapour / mixed layer, :162-166),
+ * its CO2 series (A1B ramp, :939-951) and the run sequencing (control run, :208-215) stay with the host
+ * (greb_climate_model_amd/original.py shows them).  Default 0 = the complete model = src/greb.f90. */
+#define GREB_X_NO_ICE            (1u << 0) /* log_exp <= 5: a_surf = a_no_ice (:394); heat capacity ignores sea ice (:492-495) */
+#define GREB_X_NO_HYDRO          (1u << 1) /* <= 6, 13, 15: no latent heat, evaporation, rain (:452-453) */
+#define GREB_X_NO_DEEP_OCEAN     (1u << 2) /* <= 9, 11, 14-16: dT_ocean = dTo = 0 (:513-515) */
+#define GREB_X_LW_LINEAR_VAPOR   (1u << 3) /* 11: emissivity linear in q around qclim (:423,:430) */
+#define GREB_X_NO_CIRCULATION    (1u << 4) /* <= 4: no transport of Tair and q (:553; the original's increment is
+                                              unassigned there -- defined as 0 here) */
+#define GREB_X_NO_VAPOR_TRANSPORT (1u << 5) /* 7, 16: no transport of q (:554-555; same remark) */
+#define GREB_X_VAPOR_DIFFUSION_ONLY (1u << 6) /* 8: q is diffused but not advected (:560-564) */
+#define GREB_X_SST_PLUS1         (1u << 7) /* 14-16: before every scenario step Tsurf(ocean) = Tclim(previous step's
+                                              slice) + 1 K (:226, evaluated before time_loop updates ityr);
+                                              not applied in the flux-correction phase.  The host clears it for
+                                              the control run and passes CO2 = CO2_ctrl (:225) */
+unsigned greb_log_exp_switches(int log_exp);
+/* Takes effect from the next flux_correction / run call. */
+int greb_engine_set_experiment(greb_engine* e, unsigned switches);
+
 /* Flux-correction cache: TF/qF/ToF_correct [3][730][ny][nx] + cap_surf +
  * the four state fields Ts,Ta,To,q [5][ny][nx] of one member. */
 int greb_engine_get_corrections(greb_engine* e, int member, float* corr, float* state5);
