@@ -229,6 +229,85 @@ __device__ void chain_lon(const lfloat* Trow, const lfloat* wrow, const lfloat* 
   }
 }
 
+// The same time2 sweeps for a row of exactly 64*P points (P = 6: 384x192) with the row held in REGISTERS:
+// lane l owns points P*l .. P*l+P-1, the 3+3 halo points come from the neighbouring lanes by wave rotates
+// (v_mov_b32_dpp wave_ror:1 / wave_rol:1 -- the rotate is the row's periodic boundary), the weights and the
+// wind of the row are loaded once.  No LDS traffic and no LDS round trip per sweep: the long polar chains of
+// the fine grid (up to 225 dependent sweeps per diffusion call) are bound by exactly that latency.
+__device__ __forceinline__ float wave_from_prev(float x) { // lane l <- lane l-1, lane 0 <- lane 63
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x13C /* wave_ror:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_from_next(float x) { // lane l <- lane l+1, lane 63 <- lane 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x134 /* wave_rol:1 */, 0xf, 0xf, false));
+}
+
+template <bool STRICT, int P>
+__device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfloat* urow, float cc, int time2,
+                               bool is_adv, int lane, lfloat* bufA) {
+  constexpr int NXR = 64 * P, W = P + 6;
+  float T[W], w[W], u[P];
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    int j = P * lane - 3 + i;
+    j = j < 0 ? j + NXR : (j >= NXR ? j - NXR : j);
+    w[i] = wrow[j];
+    T[i] = Trow[j];
+  }
+#pragma unroll
+  for (int i = 0; i < P; ++i) u[i] = is_adv ? urow[P * lane + i] : 0.f;
+  const bool bug_lane = lane == 63; // its point P-3 is longitude xdim-2 (1-based), src/greb.f90:881
+  for (int tt = 0; tt < time2; ++tt) {
+    if (tt > 0) { // refresh the halo from the neighbours' new values
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        T[i] = wave_from_prev(T[P + i]);         // the previous lane's last three own points
+        T[P + 3 + i] = wave_from_next(T[3 + i]); // the next lane's first three own points
+      }
+    }
+    float Tn[P];
+    if (STRICT) {
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+#pragma clang fp contract(off)
+        const int c = 3 + i;
+        float d = is_adv ? adv_lon_sub_point_strict(T, w, u[i], cc, c, bug_lane && i == P - 3)
+                         : cc * dif_S_strict(T, w, c) / 20.f;
+        if (d <= -T[c]) d = -0.9f * T[c]; // :715 / :907
+        Tn[i] = T[c] + d;
+      }
+    } else {
+      float Pp[W], Pm[W]; // Pp[m] = w[m+1]*(T[m+1]-T[m]), Pm[m] = w[m]*(T[m+1]-T[m])
+#pragma unroll
+      for (int m = 0; m < W - 1; ++m) {
+        const float e = T[m + 1] - T[m];
+        Pp[m] = w[m + 1] * e; Pm[m] = w[m] * e;
+      }
+      const float cs = cc * 0.05f;
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const int c = 3 + i;
+        float d;
+        if (is_adv) {
+          const float am = 10.f * Pm[c - 1] + (4.f * Pm[c - 2] + Pm[c - 3]);
+          float ap = 10.f * Pp[c] + (4.f * Pp[c + 1] + Pp[c + 2]);
+          if (i == P - 3) ap = bug_lane ? 10.f * Pp[c] - w[c + 3] * (T[c + 1] - T[c + 3]) : ap;
+          d = cs * (-split_p(u[i]) * ap - split_m(u[i]) * am);
+        } else {
+          const float a = Pp[c] - Pm[c - 1], b = Pp[c + 1] - Pm[c - 2], g = Pp[c + 2] - Pm[c - 3];
+          d = cs * (6.f * a + (3.f * b + g));
+        }
+        d = (d <= -T[c]) ? -0.9f * T[c] : d;
+        Tn[i] = T[c] + d;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) T[3 + i] = Tn[i];
+  }
+#pragma unroll
+  for (int i = 0; i < P; ++i) bufA[P * lane + i] = T[3 + i];
+  wave_lds_sync();
+}
+
 // complete update of one chain row by one wave.  out_row (any address space): the X_new row
 // (fused) or the dX row (dif / adv only).
 template <bool STRICT, typename OutP>
@@ -240,8 +319,13 @@ __device__ void chain_row(const Rows& X, const Rows& W, const Rows& U, const Row
   lfloat* aA = scratch + 2 * nx; // advection T1h
   lfloat* aB = scratch + 3 * nx;
   const bool do_dif = mode != kChainAdv, do_adv = mode != kChainDif;
-  if (do_dif) chain_lon<STRICT>(X.row(k), W.row(k), nullptr, rk.dif_cc, rk.dif_time2, false, nq, lane, dA, dB);
-  if (do_adv) chain_lon<STRICT>(X.row(k), W.row(k), U.row(k), rk.adv_cc, rk.adv_time2, true, nq, lane, aA, aB);
+  if (nx == 384) { // the row fits the wave's registers, 6 points per lane
+    if (do_dif) chain_lon_regs<STRICT, 6>(X.row(k), W.row(k), nullptr, rk.dif_cc, rk.dif_time2, false, lane, dA);
+    if (do_adv) chain_lon_regs<STRICT, 6>(X.row(k), W.row(k), U.row(k), rk.adv_cc, rk.adv_time2, true, lane, aA);
+  } else {
+    if (do_dif) chain_lon<STRICT>(X.row(k), W.row(k), nullptr, rk.dif_cc, rk.dif_time2, false, nq, lane, dA, dB);
+    if (do_adv) chain_lon<STRICT>(X.row(k), W.row(k), U.row(k), rk.adv_cc, rk.adv_time2, true, nq, lane, aA, aB);
+  }
   for (int q = lane; q < nq; q += 64) {
     QuadIn in;
     gather(X, W, k, q, nq, ny, do_adv, in);
