@@ -43,23 +43,78 @@ def gather_monthly(local, n_members: int, group=None):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
-def ensemble_stats(local, group=None):
-    """On-device ensemble mean and (population) variance of per-member fields across ALL ranks
-    (SURVEY.md 8f-4): two all-reduces (RCCL on the node) of the member-sum and member-sum-of-squares,
-    accumulated in fp64 so the result does not depend on how members are dealt to ranks.
-    local: [m_local, ...] -> (mean[...], var[...]) on every rank."""
+def local_moments(x):
+    """Per-element fp64 sum and sum of squares, min and max over this GPU's members: one pass of the HIP kernel
+    greb_ensemble_moments_dev over x [m_local, ...] (float32, CUDA, contiguous).  No CPU path."""
+    import ctypes as C
+
+    import torch
+
+    from . import engine
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise engine.GrebError(-1, "local_moments: needs a contiguous float32 CUDA tensor (no CPU path)")
+    m, tail = x.shape[0], tuple(x.shape[1:])
+    n = int(x[0].numel()) if m else 0
+    s1 = torch.zeros(tail, dtype=torch.float64, device=x.device)
+    s2 = torch.zeros(tail, dtype=torch.float64, device=x.device)
+    lo = torch.full(tail, float("inf"), dtype=torch.float32, device=x.device)
+    hi = torch.full(tail, float("-inf"), dtype=torch.float32, device=x.device)
+    if m:
+        f = engine.lib().greb_ensemble_moments_dev
+        f.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = f(x.data_ptr(), m, n, s1.data_ptr(), s2.data_ptr(), lo.data_ptr(), hi.data_ptr(),
+               torch.cuda.current_stream(x.device).cuda_stream)
+        if rc:
+            raise engine.GrebError(rc, "greb_ensemble_moments_dev")
+    return s1, s2, lo, hi
+
+
+def ensemble_summary(local, group=None, moments_fn=local_moments):
+    """Ensemble mean, (population) variance, min and max of per-member fields across ALL ranks:
+    each rank reduces its own members on the device (moments_fn, the HIP kernel), then three all-reduces (RCCL on
+    the node) combine the fp64 partial sums / the ranges, so the result does not depend on how members are
+    dealt to ranks.  local: [m_local, ...] -> dict of tensors [...] on every rank."""
     import torch
     import torch.distributed as dist
-    x = local.to(torch.float64)
-    s1 = x.sum(0)
-    s2 = (x * x).sum(0)
+    s1, s2, lo, hi = moments_fn(local)
     n = torch.tensor([float(local.shape[0])], dtype=torch.float64, device=local.device)
     if dist.is_available() and dist.is_initialized():
         for t in (s1, s2, n):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
     mean = s1 / n
     var = (s2 / n - mean * mean).clamp_min(0.0)
-    return mean.to(local.dtype), var.to(local.dtype)
+    return {"mean": mean.to(local.dtype), "var": var.to(local.dtype), "min": lo, "max": hi, "n": int(n.item())}
+
+
+def ensemble_stats(local, group=None, moments_fn=local_moments):
+    """(mean, variance) of ensemble_summary."""
+    s = ensemble_summary(local, group, moments_fn)
+    return s["mean"], s["var"]
+
+
+def ensemble_quantiles(x, probs):
+    """Quantiles across the members of x [n_members, ...] (all on this GPU, e.g. rank 0 after the gather), numpy's
+    default definition (linear interpolation of the order statistics): HIP kernel greb_ensemble_quantiles_dev
+    (per-point bitonic sort of the members in LDS).  Returns [len(probs), ...]."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from . import engine
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise engine.GrebError(-1, "ensemble_quantiles: needs a contiguous float32 CUDA tensor (no CPU path)")
+    pr = np.ascontiguousarray(probs, np.float32)
+    out = torch.empty((len(pr),) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    f = engine.lib().greb_ensemble_quantiles_dev
+    f.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rc = f(x.data_ptr(), x.shape[0], int(x[0].numel()), pr.ctypes.data, len(pr), out.data_ptr(),
+           torch.cuda.current_stream(x.device).cuda_stream)
+    if rc:
+        raise engine.GrebError(rc, "greb_ensemble_quantiles_dev")
+    return out
 
 
 class MonthlyGather:

@@ -21,6 +21,7 @@
 #ifndef GREB_ENGINE_H
 #define GREB_ENGINE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -175,6 +176,19 @@ int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, 
  * albedo, sw, LW_surf, LWair_down, em, Q_sens, Q_lat, Q_lat_air, dq_eva, dq_rain, dT_ocean, dTo,
  * cap_surf_new(seaice(Ts)), 0, 0.   ityr is 1-based. */
 int greb_engine_point_physics(greb_engine* e, int ityr, float co2, const float* in5, float* out15);
+
+/* ---- ensemble statistics across the members resident on one GPU -------------------
+ * The reference leaves ensemble statistics to its R scripts over per-`ens_id` files (src/greb.f90:153,
+ * 1064-1068).  x_dev: device array [n_members][n] (e.g. the monthly means viewed per member); all output
+ * pointers are device pointers of n elements (any of them may be NULL); nothing synchronises.
+ *   moments  : fp64 sum and sum of squares, min, max over the members -- the partials a multi-GPU run
+ *              all-reduces (greb_climate_model_amd/ensemble.py: mean, variance, range)
+ *   quantiles: out_dev [n_probs][n], probabilities in [0,1] (host array, <= 16), linear interpolation of the
+ *              order statistics (numpy's default); n_members <= 4096 */
+int greb_ensemble_moments_dev(const float* x_dev, int n_members, size_t n, double* sum_dev, double* sumsq_dev,
+                              float* min_dev, float* max_dev, void* stream);
+int greb_ensemble_quantiles_dev(const float* x_dev, int n_members, size_t n, const float* probs, int n_probs,
+                                float* out_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,9 +35,19 @@ def _worker(rank, world, port, n_members, q):
         local = torch.stack([torch.full((2, 12, 5, 8), float(i)) + torch.arange(8.0) for i in ids]) \
             if len(ids) else torch.zeros((0, 2, 12, 5, 8))
         out = ensemble.gather_monthly(local, n_members)
-        mean, var = ensemble.ensemble_stats(local)
+        # the per-rank member reduction is a HIP kernel (no CPU path); here only the cross-rank composition is
+        # under test, so a torch restatement of the partial moments stands in for it
+        def ref_moments(x):
+            x64 = x.to(torch.float64)
+            tail = x.shape[1:]
+            lo = x.min(0).values if x.shape[0] else torch.full(tail, float("inf"))
+            hi = x.max(0).values if x.shape[0] else torch.full(tail, float("-inf"))
+            return x64.sum(0), (x64 * x64).sum(0), lo, hi
+        summ = ensemble.ensemble_summary(local, moments_fn=ref_moments)
+        mean, var = summ["mean"], summ["var"]
         full = torch.stack([torch.full((2, 12, 5, 8), float(i)) + torch.arange(8.0) for i in range(n_members)])
         assert torch.allclose(mean, full.mean(0), atol=1e-6) and torch.allclose(var, full.var(0, unbiased=False), atol=1e-5)
+        assert torch.equal(summ["min"], full.min(0).values) and torch.equal(summ["max"], full.max(0).values) and summ["n"] == n_members
         if rank == 0:
             ok = out.shape[0] == n_members and all(
                 torch.equal(out[i], torch.full((2, 12, 5, 8), float(i)) + torch.arange(8.0)) for i in range(n_members))
