@@ -134,8 +134,10 @@ __device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q, boo
     float um[4], up[4], vm[4], vp[4]; // the sign split is shared by the two tracers
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      um[i] = fmaxf(xq.v[i], 0.f); up[i] = fminf(xq.v[i], 0.f);
-      vm[i] = fm * fmaxf(yq.v[i], 0.f); vp[i] = fp * fminf(yq.v[i], 0.f);
+      split_sign(xq.v[i], um[i], up[i]);
+      float a, b;
+      split_sign(yq.v[i], a, b);
+      vm[i] = fm * a; vp[i] = fp * b;
     }
     xn = substep_pair<SUB>(T, w, Tm2, Tm1, Tp1, Tp2, Wm2, Wm1, Wp1, Wp2, um, up, vm, vp, rk.dif_cc * 0.05f,
                            rk.dif_ccy, q == NQ - 1, calm_q);
@@ -147,15 +149,19 @@ __device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q, boo
 __device__ __forceinline__ int sub_row(int r) { return r < 9 ? 1 + r : 38 + (r - 9); } // r = 0..17
 constexpr int kSubTasks = 18 * NQ, kFullTasks = 28 * NQ;
 
-// waves 0-5: three passes each.  Pass ids 0-6 = sub passes, 7-17 = full passes; costs are balanced
-// (a sub pass costs ~1.15 full passes).  The ids are arithmetic in the wave number so they live in
-// SGPRs: a __constant__ table costs a scalar-cache load per pass inside the sub-step loop.
+// waves 0-5: three passes each.  Pass ids 0-6 = sub passes, 7-17 = full passes (a sub pass costs ~1.5 full
+// passes: 340 vs 228 instructions).  Waves w and w+4 share a SIMD, and SIMDs 2 and 3 also carry the polar
+// waves 6 and 7 (~900 instructions per sub-step each), so waves 2 and 3 get the light end of the deal:
+//   wave:  0        1        2         3           4          5
+//          0,1,7    2,3,8    4,9,10    11,12,13    5,14,15    6,16,17
+//   SIMD:  0: 3 sub + 3 full   1: 3 sub + 3 full   2: 1 sub + 2 full + pole   3: 3 full + pole
+// The ids are arithmetic in the wave number so they live in SGPRs: a __constant__ table costs a scalar-cache
+// load per pass inside the sub-step loop.
 __device__ __forceinline__ int pass_of(int wave, int i) {
-  // wave: 0        1        2        3          4           5
-  //       0,1,7    2,3,8    4,5,9    6,10,11    12,13,14    15,16,17
-  if (wave < 3) return i < 2 ? 2 * wave + i : 7 + wave;
-  if (wave == 3) return i == 0 ? 6 : 9 + i;
-  return 12 + 3 * (wave - 4) + i;
+  if (wave < 2) return i < 2 ? 2 * wave + i : 7 + wave;
+  if (wave == 2) return i == 0 ? 4 : 8 + i;
+  if (wave == 3) return 11 + i;
+  return i == 0 ? wave + 1 : 14 + 2 * (wave - 4) + (i - 1);
 }
 
 template <bool STRICT>

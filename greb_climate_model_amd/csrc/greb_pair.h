@@ -43,6 +43,20 @@ __device__ __forceinline__ q8 zero8() {
   return r;
 }
 
+// a - b as ONE packed instruction.  Left to itself the compiler lowers the latitudinal differences of lat2()
+// to two scalar v_sub_f32 each (32 per task); the sub-step loop is VALU-issue bound, so that is 16 wasted slots.
+__device__ __forceinline__ v2 pk_sub(v2 a, v2 b) {
+  v2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max(u,0) / min(u,0) of a finite wind: v_med3_f32 needs no canonicalising v_max(x,x) in front (fmaxf does),
+// and min(u,0) = u - max(u,0) exactly
+__device__ __forceinline__ void split_sign(float u, float& pos, float& neg) {
+  pos = __builtin_amdgcn_fmed3f(u, 0.f, 3.0e38f); // (an infinite bound is folded back into v_max)
+  neg = u - pos;
+}
+
 struct Flux2 {
   v2 Pp[10]; // Pp[m] = w[m+1]*(T[m+1]-T[m]), m = 4..9
   v2 Pm[10]; // Pm[m] = w[m]  *(T[m+1]-T[m]), m = 1..6
@@ -113,8 +127,8 @@ __device__ __forceinline__ void lat2(const v2 T0[4], const v2 Tm2[4], const v2 T
                                      v2 ddif[4], v2 dadv[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const v2 gm1 = wm1[i] * (Tm1[i] - T0[i]), gp1 = wp1[i] * (Tp1[i] - T0[i]);
-    const v2 dm2 = wm2[i] * (T0[i] - Tm2[i]), dp2 = wp2[i] * (T0[i] - Tp2[i]);
+    const v2 gm1 = wm1[i] * pk_sub(Tm1[i], T0[i]), gp1 = wp1[i] * pk_sub(Tp1[i], T0[i]);
+    const v2 dm2 = wm2[i] * pk_sub(T0[i], Tm2[i]), dp2 = wp2[i] * pk_sub(T0[i], Tp2[i]);
     ddif[i] = ccy_dif * (gm1 + gp1);
     dadv[i] = vp[i] * (dp2 - gp1) - vm[i] * (dm2 - gm1);
   }
