@@ -231,7 +231,9 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, bo
   v2 Th[2][2]; // [diffusion, advection][point]
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
-    const int time2 = which ? rk.adv_time2 : rk.dif_time2;
+    // the row constants come from LDS (per lane) but are the same in every lane: a scalar trip count keeps the
+    // sweep loop free of exec-mask bookkeeping
+    const int time2 = __builtin_amdgcn_readfirstlane(which ? rk.adv_time2 : rk.dif_time2);
     const float cc = which ? rk.adv_cc : rk.dif_cc;
     v2 T[10];
 #pragma unroll
