@@ -5,7 +5,7 @@
 // (src/greb.f90:239-364, 528-553) without leaving the CU.
 //
 // Residency
-//   LDS (150 KB)  X[2 buffers][48][96][{Tair,q}]  the two transported tracers, INTERLEAVED and
+//   LDS (157 KB)  X[2 buffers][48][96][{Tair,q}]  the two transported tracers, INTERLEAVED and
 //                                                 double-buffered
 //                 W[48][96][{wz_air,wz_vapor}]    the stencil weights (static for the run)
 //                 WX, WY [48][96]                 this step's winds, scaled by the row's advection
@@ -40,11 +40,15 @@ constexpr int NX = 96, NY = 48, NQ = 24, NP = 4608;
 constexpr int kThreads = 512;
 constexpr int RS = 2 * NX; // floats per interleaved row
 // LDS map, in floats
-constexpr int kOffX = 0;            // [2][NP][2]
-constexpr int kOffW = 4 * NP;       // [NP][2]
-constexpr int kOffWX = 6 * NP;      // [NP]  cu*u   (raw u in rows 0, 47 and in STRICT)
-constexpr int kOffWY = 7 * NP;      // [NP]  ccy/3*v (raw v ...)
-constexpr int kOffScr = 8 * NP;     // [2 poles][2][RS]
+// X buffers and W carry one all-zero GUARD row below row 0 and above row NY-1: the rows k-2 .. k+2 of any bulk
+// row are then five rows at constant strides from ONE base address (immediate offsets of the ds_read), and the
+// missing neighbours of rows 1 and NY-2 multiply to zero without selects.
+constexpr int XB = (NY + 2) * RS;   // floats per guarded buffer
+constexpr int kOffX = RS;           // row 0 of X[0]; X[b] row k at kOffX + b*XB + k*RS
+constexpr int kOffW = 2 * XB + RS;  // row 0 of W  [NY][NX][{wz_air,wz_vapor}]
+constexpr int kOffWX = 3 * XB;      // [NP]  cu*u   (raw u in rows 0, 47 and in STRICT)
+constexpr int kOffWY = kOffWX + NP; // [NP]  ccy/3*v (raw v ...)
+constexpr int kOffScr = kOffWY + NP; // [2 poles][2][RS]
 constexpr int kOffRowK = kOffScr + 4 * RS; // [NY][kRowKWords]
 constexpr int kLdsFloats = kOffRowK + NY * kRowKWords;
 constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
@@ -76,27 +80,43 @@ __device__ __forceinline__ q8 zip(const f4& a, const f4& b) {
 // ---------------------------------------------------------------------------------------------
 // one bulk task: pair-quad (k, q) -> X_new = (X + dX_diffuse) + dX_advec, both tracers
 // ---------------------------------------------------------------------------------------------
+// A lane's bulk task of one pass, fixed for the whole launch: float offsets (inside a guarded buffer) of its own
+// pair-quad and of the quads to its left and right, and (row | quad << 8).  Computed once (make_tasks) and kept in
+// VGPRs: recomputing them -- a division by 24, wrap-around selects and a dozen address adds -- cost ~15 % of a
+// pass's issue slots in the sub-step loop.
+struct TaskAddr { int c, l, r, kq; };
+
+// a pair-quad at a float offset p (two dwordx4: the [half][quad][4] row layout of greb_pair.h)
+__device__ __forceinline__ q8 ld8p(const lfloat* p) {
+  const vfloat4 a = *(const __attribute__((address_space(3))) vfloat4*)p;
+  const vfloat4 b = *(const __attribute__((address_space(3))) vfloat4*)(p + kHalfRow);
+  q8 r;
+  r.v[0] = v2{a.x, a.y}; r.v[1] = v2{a.z, a.w}; r.v[2] = v2{b.x, b.y}; r.v[3] = v2{b.z, b.w};
+  return r;
+}
+
 template <bool STRICT, bool SUB>
-__device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q, bool calm_q = false) {
-  const int qm = q == 0 ? NQ - 1 : q - 1, qp = q == NQ - 1 ? 0 : q + 1;
-  const lfloat* Xc = lds + kOffX + cur * 2 * NP;
+__device__ __forceinline__ void row_task(lfloat* lds, int cur, const TaskAddr& ta, bool calm_q = false) {
+  const int k = ta.kq & 255, q = ta.kq >> 8;
+  const lfloat* Xc = lds + kOffX + cur * XB;
   const lfloat* Wc = lds + kOffW;
-  const lfloat* xr = Xc + k * RS;
-  const lfloat* wr = Wc + k * RS;
-  // rows beyond the grid do not occur for bulk rows 1..46 except k-2 = -1 / k+2 = 48: clamp the row,
-  // zero the weight
-  const int km2 = k >= 2 ? k - 2 : k, kp2 = k <= NY - 3 ? k + 2 : k;
-  const q8 LT = ld8(xr, qm), CT = ld8(xr, q), RT = ld8(xr, qp);
-  const q8 Tm1 = ld8(xr - RS, q), Tp1 = ld8(xr + RS, q);
-  const q8 Tm2 = ld8(Xc + km2 * RS, q), Tp2 = ld8(Xc + kp2 * RS, q);
-  const q8 LW = ld8(wr, qm), CW = ld8(wr, q), RW = ld8(wr, qp);
-  const q8 Wm1 = ld8(wr - RS, q), Wp1 = ld8(wr + RS, q);
-  const q8 Wm2 = k >= 2 ? ld8(Wc + km2 * RS, q) : zero8();
-  const q8 Wp2 = k <= NY - 3 ? ld8(Wc + kp2 * RS, q) : zero8();
-  const f4 xq = ld4(lds + kOffWX + k * NX + 4 * q), yq = ld4(lds + kOffWY + k * NX + 4 * q);
   const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
+  const f4 xq = ld4(lds + kOffWX + k * NX + 4 * q), yq = ld4(lds + kOffWY + k * NX + 4 * q);
   q8 xn;
   if (STRICT) {
+    const int qm = q == 0 ? NQ - 1 : q - 1, qp = q == NQ - 1 ? 0 : q + 1;
+    const lfloat* xr = Xc + k * RS;
+    const lfloat* wr = Wc + k * RS;
+    // rows beyond the grid do not occur for bulk rows 1..46 except k-2 = -1 / k+2 = 48: clamp the row,
+    // zero the weight
+    const int km2 = k >= 2 ? k - 2 : k, kp2 = k <= NY - 3 ? k + 2 : k;
+    const q8 LT = ld8(xr, qm), CT = ld8(xr, q), RT = ld8(xr, qp);
+    const q8 Tm1 = ld8(xr - RS, q), Tp1 = ld8(xr + RS, q);
+    const q8 Tm2 = ld8(Xc + km2 * RS, q), Tp2 = ld8(Xc + kp2 * RS, q);
+    const q8 LW = ld8(wr, qm), CW = ld8(wr, q), RW = ld8(wr, qp);
+    const q8 Wm1 = ld8(wr - RS, q), Wp1 = ld8(wr + RS, q);
+    const q8 Wm2 = k >= 2 ? ld8(Wc + km2 * RS, q) : zero8();
+    const q8 Wp2 = k <= NY - 3 ? ld8(Wc + kp2 * RS, q) : zero8();
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr) {
       QuadIn in;
@@ -123,6 +143,13 @@ __device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q, boo
       }
     }
   } else {
+    // five rows k-2 .. k+2 of the own column from ONE base (the guard rows make k-2 = -1 and k+2 = NY valid,
+    // zero-weighted reads), the row's left and right quads from the two precomputed offsets
+    const lfloat* xb = Xc + ta.c - 2 * RS;
+    const lfloat* wb = Wc + ta.c - 2 * RS;
+    const q8 Tm2 = ld8p(xb), Tm1 = ld8p(xb + RS), CT = ld8p(xb + 2 * RS), Tp1 = ld8p(xb + 3 * RS), Tp2 = ld8p(xb + 4 * RS);
+    const q8 Wm2 = ld8p(wb), Wm1 = ld8p(wb + RS), CW = ld8p(wb + 2 * RS), Wp1 = ld8p(wb + 3 * RS), Wp2 = ld8p(wb + 4 * RS);
+    const q8 LT = ld8p(Xc + ta.l), RT = ld8p(Xc + ta.r), LW = ld8p(Wc + ta.l), RW = ld8p(Wc + ta.r);
     v2 T[12], w[12];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -142,7 +169,15 @@ __device__ __forceinline__ void row_task(lfloat* lds, int cur, int k, int q, boo
     xn = substep_pair<SUB>(T, w, Tm2, Tm1, Tp1, Tp2, Wm2, Wm1, Wp1, Wp2, um, up, vm, vp, rk.dif_cc * 0.05f,
                            rk.dif_ccy, q == NQ - 1, calm_q);
   }
-  st8(lds + kOffX + (cur ^ 1) * 2 * NP + k * RS, q, xn);
+  // own quad of the other buffer: same offset
+  {
+    lfloat* o = lds + kOffX + (cur ^ 1) * XB + ta.c;
+    vfloat4 a, b;
+    a.x = xn.v[0].x; a.y = xn.v[0].y; a.z = xn.v[1].x; a.w = xn.v[1].y;
+    b.x = xn.v[2].x; b.y = xn.v[2].y; b.z = xn.v[3].x; b.w = xn.v[3].y;
+    *(__attribute__((address_space(3))) vfloat4*)o = a;
+    *(__attribute__((address_space(3))) vfloat4*)(o + kHalfRow) = b;
+  }
 }
 
 // task index -> row
@@ -164,17 +199,43 @@ __device__ __forceinline__ int pass_of(int wave, int i) {
   return i == 0 ? wave + 1 : 14 + 2 * (wave - 4) + (i - 1);
 }
 
+struct BulkTasks { TaskAddr t[3]; };
+// once per launch; the asm makes the values opaque, so the compiler keeps them instead of re-deriving them from
+// the lane id inside the sub-step loop
+__device__ __forceinline__ BulkTasks make_tasks(int wave, int lane) {
+  BulkTasks b;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int pass = pass_of(wave < 6 ? wave : 0, i);
+    int k = 1, q = 0, valid = 0;
+    if (pass < 7) {
+      const int t = pass * 64 + lane;
+      valid = t < kSubTasks; k = sub_row((valid ? t : 0) / NQ); q = (valid ? t : 0) % NQ;
+    } else {
+      const int t = (pass - 7) * 64 + lane;
+      valid = t < kFullTasks; k = 10 + (valid ? t : 0) / NQ; q = (valid ? t : 0) % NQ;
+    }
+    TaskAddr a;
+    a.c = k * RS + 4 * q;
+    a.l = k * RS + 4 * (q == 0 ? NQ - 1 : q - 1);
+    a.r = k * RS + 4 * (q == NQ - 1 ? 0 : q + 1);
+    a.kq = valid ? (k | (q << 8)) : -1;
+    asm volatile("" : "+v"(a.c), "+v"(a.l), "+v"(a.r), "+v"(a.kq));
+    b.t[i] = a;
+  }
+  return b;
+}
+
 template <bool STRICT>
-__device__ __forceinline__ void bulk_substep(lfloat* lds, int cur, int wave, int lane, int dbg, bool calm_q = false) {
+__device__ __forceinline__ void bulk_substep(lfloat* lds, int cur, int wave, const BulkTasks& tasks, int dbg, bool calm_q = false) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int pass = __builtin_amdgcn_readfirstlane(pass_of(wave, i));
+    if (tasks.t[i].kq < 0) continue;
     if (pass < 7) {
-      const int t = pass * 64 + lane;
-      if (t < kSubTasks && !(dbg & 1)) row_task<STRICT, true>(lds, cur, sub_row(t / NQ), t % NQ, calm_q);
+      if (!(dbg & 1)) row_task<STRICT, true>(lds, cur, tasks.t[i], calm_q);
     } else {
-      const int t = (pass - 7) * 64 + lane;
-      if (t < kFullTasks && !(dbg & 2)) row_task<STRICT, false>(lds, cur, 10 + t / NQ, t % NQ, calm_q);
+      if (!(dbg & 2)) row_task<STRICT, false>(lds, cur, tasks.t[i], calm_q);
     }
   }
 }
@@ -205,7 +266,7 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, bo
   if (l >= 48) return; // idle lanes (no workgroup barrier inside this function)
   const int k = pole ? NY - 1 : 0;
   const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
-  const lfloat* Xc = lds + kOffX + cur * 2 * NP;
+  const lfloat* Xc = lds + kOffX + cur * XB;
   const lfloat* Wc = lds + kOffW;
   lfloat* bufA = lds + kOffScr + pole * 2 * RS;
   lfloat* bufB = bufA + RS;
@@ -344,7 +405,7 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, bo
       xn[pt] = (own[pt] + dd) + da;
     }
   }
-  st_pair2(lds + kOffX + (cur ^ 1) * 2 * NP + k * RS + pair_off(l), xn[0], xn[1]);
+  st_pair2(lds + kOffX + (cur ^ 1) * XB + k * RS + pair_off(l), xn[0], xn[1]);
 }
 
 // stage this step's winds (src/greb.f90:203-216, 732): raw for STRICT and for the polar rows,
@@ -369,8 +430,15 @@ __device__ __forceinline__ void stage_winds(lfloat* lds, const float* __restrict
 // the circulation loop shared by the member kernel and its test mirror
 template <bool STRICT>
 struct Circ {
+  BulkTasks tasks;
   __device__ __forceinline__ void init(lfloat* lds, const float* wz_air, const float* wz_vapor,
                                        const RowTables* __restrict__ tab) {
+    tasks = make_tasks(threadIdx.x >> 6, threadIdx.x & 63);
+    // guard rows of X[0], X[1], W: zero, never written again
+    for (int i = threadIdx.x; i < 6 * RS; i += kThreads) {
+      const int g = i / RS, o = i % RS; // buffer g >> 1, lower / upper guard g & 1
+      lds[(g >> 1) * XB + (g & 1) * (NY + 1) * RS + o] = 0.f;
+    }
     stage_row_consts(lds + kOffRowK, *tab, NY);
     for (int i = threadIdx.x; i < NP / 4; i += kThreads)
       st8(lds + kOffW + (i / NQ) * RS, i % NQ, zip(ld4(wz_air + 4 * i), ld4(wz_vapor + 4 * i)));
@@ -378,8 +446,8 @@ struct Circ {
 
   // dbg: timing experiments only (tools/microbench_circ.py): bit0/1/2 skip sub / full / chain work
   __device__ __forceinline__ void substep(lfloat* lds, int cur, int dbg = 0, bool calm_q = false) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave < 6) bulk_substep<STRICT>(lds, cur, wave, lane, dbg, calm_q);
+    const int wave = threadIdx.x >> 6;
+    if (wave < 6) bulk_substep<STRICT>(lds, cur, wave, tasks, dbg, calm_q);
     else if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, wave - 6, calm_q);
   }
 };
@@ -415,7 +483,7 @@ __global__ __launch_bounds__(kThreads) void circulation_g96_kernel(const float* 
     cur ^= 1;
   }
   for (int i = threadIdx.x; i < NP / 4; i += kThreads) {
-    const f4 a = comp(ld8(lds + kOffX + cur * 2 * NP + (i / NQ) * RS, i % NQ), 0), b = ld4(Xin + fo + 4 * i);
+    const f4 a = comp(ld8(lds + kOffX + cur * XB + (i / NQ) * RS, i % NQ), 0), b = ld4(Xin + fo + 4 * i);
     st4(dX + fo + 4 * i, f4{{a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2], a.v[3] - b.v[3]}}); // :551
   }
 }
@@ -473,8 +541,8 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     // ---- point physics on the OLD state + Euler update (:254-268 / :328-361)
     const Phys P = a.phys[m];
     const float co2 = FLUX ? a.co2_flux : a.co2[(size_t)m * a.co2_stride + a.co2_year0 + yr_rel]; // :924
-    lfloat* Xf = lds + kOffX + cur * 2 * NP;       // the tracers after the 24 sub-steps
-    lfloat* red = lds + kOffX + (cur ^ 1) * 2 * NP; // idle buffer: annual-mean reduction scratch
+    lfloat* Xf = lds + kOffX + cur * XB;       // the tracers after the 24 sub-steps
+    lfloat* red = lds + kOffX + (cur ^ 1) * XB; // idle buffer: annual-mean reduction scratch
     // Each thread takes whole quads (4 consecutive longitudes): every load/store of the ~26
     // fields a point touches is one dwordx4 and all of a quad's loads are in flight together, so
     // a step pays ~3 dependent HBM/L2 round trips per thread instead of 9.
