@@ -75,11 +75,33 @@ def main():
     eng.flux_correction(1)  # shared by all members (same physics): one member integrated, state broadcast
     np_ = eng.np
     monthly = torch.empty((M, K, 12, 5, np_), dtype=torch.float32, device="cuda")
-    if W > 0:
-        wbuf = torch.empty((M, W, 12, 5, np_), dtype=torch.float32, device="cuda")
-        eng.run(W, np.repeat(levels[:, None], W, 1), monthly_dev_ptr=wbuf.data_ptr())
-        del wbuf
     gathered = None
+
+    def years_with_gather(n_years, bufs, g):
+        """n_years model years, one engine call per year; year y's gather (RCCL over xGMI) overlaps year y+1."""
+        for y in range(n_years):
+            eng.run(1, levels[:, None], monthly_dev_ptr=bufs[y].data_ptr())
+            g.submit(y, bufs[y][:, 0])
+        return g.finish()
+
+    if world == 1:
+        if W > 0:
+            wbuf = torch.empty((M, W, 12, 5, np_), dtype=torch.float32, device="cuda")
+            eng.run(W, np.repeat(levels[:, None], W, 1), monthly_dev_ptr=wbuf.data_ptr())
+            del wbuf
+    else:
+        # the warm-up takes the timed path, gather included: the first collective of a kind creates RCCL's
+        # peer-to-peer channels (seconds), which must not land in the timed years.  W = 0 still warms the
+        # channels with one small gather.
+        wy = max(W, 1)
+        wshape = (M, 1, 12, 5, np_) if W > 0 else (1, 1, 1, 1, 8)
+        wbufs = [torch.zeros(wshape, dtype=torch.float32, device="cuda") for _ in range(wy)]
+        wg = ensemble.MonthlyGather(wshape[0], wy, wshape[2:], torch.float32, "cuda")
+        if W > 0:
+            years_with_gather(W, wbufs, wg)
+        else:
+            wg.submit(0, wbufs[0][:, 0]); wg.finish()
+        del wbufs, wg
 
     def barrier():
         torch.cuda.synchronize()
@@ -95,10 +117,7 @@ def main():
     if world == 1:
         eng.run(K, np.repeat(levels[:, None], K, 1), monthly_dev_ptr=monthly.data_ptr())
     else:
-        for y in range(K):  # year y's gather (RCCL over xGMI) overlaps year y+1's integration
-            eng.run(1, levels[:, None], monthly_dev_ptr=year_bufs[y].data_ptr())
-            gather.submit(y, year_bufs[y][:, 0])
-        gathered = gather.finish()
+        gathered = years_with_gather(K, year_bufs, gather)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
