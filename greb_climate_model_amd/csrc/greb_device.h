@@ -287,6 +287,15 @@ __device__ __forceinline__ void lat_pm(const f4& T0, const f4& Tm2, const f4& Tm
   }
 }
 
+// Sum over the 64 lanes of a wavefront by shuffles (ds_bpermute butterflies); every lane gets the total.
+// Used for the diagnostic global mean (src/greb.f90:954) in FAST arithmetic; STRICT keeps the reference's
+// sequential order, which is what flang's sum() lowers to.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 // ============================================================================================
 // Point physics (src/greb.f90:367-525).  One column of the model; everything fp32.
 // STRICT keeps the reference's operation order (x**4 = ((x*x)*x)*x as flang -O2 lowers it); the

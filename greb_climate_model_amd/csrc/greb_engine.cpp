@@ -191,7 +191,7 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     b.it0 = it; b.nsteps = 1; // the step kernel derives its clock from it0; year indices are those of `a`
     HIP_TRY(e, launch_physics_step(b, cur, e->Xa, e->red, nrun, e->strict, e->stream));
     if (ityr == kNT && a.yearly)
-      HIP_TRY(e, launch_yearly(e->red, a.yearly, e->np, e->nx, a.ipx, a.ipy, a.yearly_years, a.yearly_year0, nrun, e->stream));
+      HIP_TRY(e, launch_yearly(e->red, a.yearly, e->np, e->nx, a.ipx, a.ipy, a.yearly_years, a.yearly_year0, nrun, e->strict, e->stream));
   }
   return 0;
 }

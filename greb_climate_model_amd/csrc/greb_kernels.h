@@ -66,7 +66,7 @@ hipError_t launch_substep_fused(const float* X, const float* W2, const float* u,
 hipError_t launch_physics_step(const MemberArgs& a, const float* X, float* Xout, float* red, int n_members,
                                bool strict, hipStream_t s);
 hipError_t launch_yearly(const float* red, float* yearly, int np, int nx, int ipx, int ipy, int yearly_years,
-                         int year_index, int n_members, hipStream_t s);
+                         int year_index, int n_members, bool strict, hipStream_t s);
 hipError_t launch_pack_tracers(const float* state, float* X, int np, int n_members, hipStream_t s);
 
 struct PointArgs {

@@ -386,7 +386,26 @@ hipError_t launch_physics_step(const MemberArgs& a, const float* X, float* Xout,
 }
 
 // diagnostics at the end of a model year (src/greb.f90:948-954): the reference's sum() is a
-// sequential fp32 loop; one thread per member reproduces that order
+// sequential fp32 loop; one thread per member reproduces that order (STRICT)
+// FAST arithmetic: one 256-thread workgroup per member, per-lane partial sums + wavefront shuffle reduction
+__global__ __launch_bounds__(256) void yearly_reduce_kernel(const float* __restrict__ red, float* __restrict__ yearly,
+                                                            int np, int nx, int ipx, int ipy, int yearly_years,
+                                                            int year_index) {
+  __shared__ float wsum[4];
+  const int m = blockIdx.x;
+  const float* r = red + (size_t)m * np;
+  float part = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) part += r[i];
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* y = yearly + ((size_t)m * yearly_years + year_index) * 2;
+    y[0] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)np - 273.15f; // :954
+    y[1] = r[(ipy - 1) * nx + (ipx - 1)] - 273.15f;
+  }
+}
+
 __global__ void yearly_kernel(const float* __restrict__ red, float* __restrict__ yearly, int np, int nx, int ipx,
                               int ipy, int yearly_years, int year_index, int n_members) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,7 +422,12 @@ __global__ void yearly_kernel(const float* __restrict__ red, float* __restrict__
 }
 
 hipError_t launch_yearly(const float* red, float* yearly, int np, int nx, int ipx, int ipy, int yearly_years,
-                         int year_index, int n_members, hipStream_t s) {
+                         int year_index, int n_members, bool strict, hipStream_t s) {
+  if (!strict) {
+    hipLaunchKernelGGL(yearly_reduce_kernel, dim3(n_members), dim3(256), 0, s, red, yearly, np, nx, ipx, ipy, yearly_years,
+                       year_index);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(yearly_kernel, dim3((n_members + 63) / 64), dim3(64), 0, s, red, yearly, np, nx, ipx, ipy,
                      yearly_years, year_index, n_members);
   return hipGetLastError();

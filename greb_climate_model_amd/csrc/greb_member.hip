@@ -556,13 +556,30 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     }
     if (ityr == kNT) {
       __syncthreads();
-      if (tid == 0 && a.yearly) {
+      if (STRICT) {
+        if (tid == 0 && a.yearly) {
 #pragma clang fp contract(off)
-        float sum = 0.f; // the reference's sum() lowers to a sequential fp32 loop; same order here
-        for (int i = 0; i < NP; ++i) sum += red[i];
-        float* y = a.yearly + ((size_t)m * a.yearly_years + (a.yearly_year0 + yr_rel)) * 2;
-        y[0] = sum / (float)NP - 273.15f;                                               // :954
-        y[1] = red[(a.ipy - 1) * NX + (a.ipx - 1)] - 273.15f;
+          float sum = 0.f; // the reference's sum() lowers to a sequential fp32 loop; same order here
+          for (int i = 0; i < NP; ++i) sum += red[i];
+          float* y = a.yearly + ((size_t)m * a.yearly_years + (a.yearly_year0 + yr_rel)) * 2;
+          y[0] = sum / (float)NP - 273.15f;                                               // :954
+          y[1] = red[(a.ipy - 1) * NX + (a.ipx - 1)] - 273.15f;
+        }
+      } else if (a.yearly) { // FAST: per-lane partial sums, wavefront shuffle reduction, 8 wave totals through LDS
+        float part = 0.f;
+        for (int i = tid; i < NP; i += kThreads) part += red[i];
+        part = wave_sum(part);
+        const float point = red[(a.ipy - 1) * NX + (a.ipx - 1)];
+        __syncthreads(); // everyone has read red[]; its first words now carry the wave totals
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        if (tid == 0) {
+          float sum = 0.f;
+          for (int w = 0; w < kThreads / 64; ++w) sum += red[w];
+          float* y = a.yearly + ((size_t)m * a.yearly_years + (a.yearly_year0 + yr_rel)) * 2;
+          y[0] = sum / (float)NP - 273.15f;                                               // :954
+          y[1] = point - 273.15f;
+        }
       }
     }
     __syncthreads();
