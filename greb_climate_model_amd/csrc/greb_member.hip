@@ -241,6 +241,16 @@ __device__ __forceinline__ int pass_of(int wave, int i) {
 
 struct BulkTasks { TaskAddr t[3]; };
 
+// Wave roles.  Waves w and w+4 share a SIMD, and the SIMD's issue arbiter favours the OLDER wave: the younger one
+// runs in the slots the older leaves.  So the heavy job of every SIMD sits on its older wave -- the heavy bulk
+// slots on waves 0 and 1, the two polar chains (~800 instructions, a dependent chain of 8 sweeps) on waves 2 and
+// 3 -- and the light bulk slots on waves 4-7.  Measured over 28 random deals of the same passes with equal SIMD
+// sums: 3 045 to 3 424 yr/s, best when the older wave of a pair carries ~880 and the younger ~500 instructions,
+// worst the other way round.
+// bulk slot s = 0..5 of the schedules below: slots 0, 1 -> waves 0, 1; slots 2, 3 (the SIMDs that also carry a
+// polar wave) -> waves 6, 7; slots 4, 5 -> waves 4, 5.
+__device__ __forceinline__ int bulk_slot(int wave) { return wave >= 6 ? wave - 4 : wave; }
+
 // FAST schedule.  Task kinds: one row (S1 sub-cycled family, F1 full family) or two stacked rows (ST, FT).
 //   ST  rows (1,2) (3,4) (5,6) (7,8) (39,40) .. (45,46) : 8 pairs x 24 quads = 3 full passes
 //   FT  rows (10,11) .. (24,25)                          : 8 pairs x 24 quads = 3 full passes
@@ -283,7 +293,7 @@ __device__ __forceinline__ BulkTasks make_tasks(int wave, int lane) {
   for (int i = 0; i < 3; ++i) {
     int k = 1, q = 0, valid = 0;
     if (STRICT) { // one row per task, 18 passes (pass_of)
-      const int pass = pass_of(wave < 6 ? wave : 0, i);
+      const int pass = pass_of(wave, i);
       if (pass < 7) {
         const int t = pass * 64 + lane;
         valid = t < kSubTasks; k = sub_row((valid ? t : 0) / NQ); q = (valid ? t : 0) % NQ;
@@ -292,7 +302,7 @@ __device__ __forceinline__ BulkTasks make_tasks(int wave, int lane) {
         valid = t < kFullTasks; k = 10 + (valid ? t : 0) / NQ; q = (valid ? t : 0) % NQ;
       }
     } else {
-      const int w6 = wave < 6 ? wave : 0, kind = fast_kind(w6, i), t = fast_index(w6, i) * 64 + lane;
+      const int w6 = wave, kind = fast_kind(w6, i), t = fast_index(w6, i) * 64 + lane;
       const int r = t / NQ;
       q = t % NQ;
       if (kind == kST) { valid = r < 8; k = r < 4 ? 1 + 2 * r : 39 + 2 * (r - 4); }
@@ -528,7 +538,7 @@ struct Circ {
   BulkTasks tasks;
   __device__ __forceinline__ void init(lfloat* lds, const float* wz_air, const float* wz_vapor,
                                        const RowTables* __restrict__ tab) {
-    tasks = make_tasks<STRICT>(threadIdx.x >> 6, threadIdx.x & 63);
+    tasks = make_tasks<STRICT>(bulk_slot(threadIdx.x >> 6), threadIdx.x & 63);
     // guard rows of X[0], X[1], W: zero, never written again
     for (int i = threadIdx.x; i < 6 * RS; i += kThreads) {
       const int g = i / RS, o = i % RS; // buffer g >> 1, lower / upper guard g & 1
@@ -542,8 +552,8 @@ struct Circ {
   // dbg: timing experiments only (tools/microbench_circ.py): bit0/1/2 skip sub / full / chain work
   __device__ __forceinline__ void substep(lfloat* lds, int cur, int dbg = 0, bool calm_q = false) {
     const int wave = threadIdx.x >> 6;
-    if (wave < 6) bulk_substep<STRICT>(lds, cur, wave, tasks, dbg, calm_q);
-    else if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, wave - 6, calm_q);
+    if (wave == 2 || wave == 3) { if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, wave - 2, calm_q); }
+    else bulk_substep<STRICT>(lds, cur, bulk_slot(wave), tasks, dbg, calm_q);
   }
 };
 
