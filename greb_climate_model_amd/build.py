@@ -42,23 +42,28 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
 
 def build_host(verbose: bool = False) -> str | None:
-    """The thin Fortran host (greb_host.f90, iso_c_binding) -> greb_climate_model_amd/greb_host.
-    Returns None when no Fortran compiler is present."""
+    """The thin Fortran hosts over iso_c_binding: greb_host (src/greb.f90's shell) and greb_host_original (the
+    upstream variant's shell with the log_exp experiments) -> greb_climate_model_amd/.  Returns greb_host's
+    path, or None when no Fortran compiler is present."""
     fc = shutil.which("amdflang") or ("/opt/rocm/bin/amdflang" if os.path.exists("/opt/rocm/bin/amdflang") else None)
-    src = os.path.join(PKG, "host", "greb_host.f90")
-    if fc is None or not os.path.exists(src):
+    api = os.path.join(PKG, "host", "greb_c_api.f90")
+    if fc is None or not os.path.exists(api):
         return None
-    out = os.path.join(PKG, "greb_host")
-    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
-        return out
     moddir = os.path.join(PKG, "host", "_mod")
     os.makedirs(moddir, exist_ok=True)
-    cmd = [fc, "-O2", "-module-dir", moddir, "-o", out, src, "-L" + PKG, "-lgreb_hip", "-Wl,-rpath," + PKG,
-           "-Wl,-rpath,$ORIGIN"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    return out
+    first = None
+    for name in ("greb_host", "greb_host_original"):
+        src = os.path.join(PKG, "host", name + ".f90")
+        out = os.path.join(PKG, name)
+        first = first or out
+        if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(api), os.path.getmtime(LIB)):
+            continue
+        cmd = [fc, "-O2", "-module-dir", moddir, "-o", out, api, src, "-L" + PKG, "-lgreb_hip", "-Wl,-rpath," + PKG,
+               "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return first
 
 
 if __name__ == "__main__":

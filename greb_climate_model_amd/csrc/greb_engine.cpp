@@ -500,6 +500,11 @@ int greb_engine_set_corrections(greb_engine* e, int member, const float* corr, c
   return 0;
 }
 
+int greb_engine_set_state(greb_engine* e, int member, const float* state5) {
+  if (!state5) return fail(e, GREB_E_INVALID, "set_state: bad argument");
+  return greb_engine_set_corrections(e, member, nullptr, state5);
+}
+
 // ---------------------------------------------------------------- batched single routines
 namespace {
 struct DevBuf {

@@ -42,7 +42,7 @@ EXPORTS = ["greb_params_default", "greb_engine_create", "greb_engine_flux_correc
            "greb_engine_last_error", "greb_engine_destroy", "greb_device_info", "greb_diffusion_batched",
            "greb_advection_batched", "greb_circulation_batched", "greb_diffusion_batched_dev",
            "greb_engine_point_physics", "greb_log_exp_switches", "greb_engine_set_experiment",
-           "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev"]
+           "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev", "greb_engine_set_state"]
 
 
 def _check(rc: int, h=None):

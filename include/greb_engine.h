@@ -138,8 +138,10 @@ int greb_engine_set_experiment(greb_engine* e, unsigned switches);
 int greb_engine_get_corrections(greb_engine* e, int member, float* corr, float* state5);
 int greb_engine_set_corrections(greb_engine* e, int member, const float* corr, const float* state5);
 
-/* Current state of one member: Ts, Ta, To, q, cap_surf [5][ny][nx]. */
+/* Current state of one member: Ts, Ta, To, q, cap_surf [5][ny][nx]; set: member -1 = every member
+ * (== greb_engine_set_corrections(e, member, NULL, state5), for hosts that cannot pass a null array). */
 int greb_engine_get_state(greb_engine* e, int member, float* state5);
+int greb_engine_set_state(greb_engine* e, int member, const float* state5);
 
 const char* greb_engine_last_error(const greb_engine* e);
 int greb_engine_destroy(greb_engine* e);

@@ -64,3 +64,31 @@ def test_host_flux_correction_cache(tmp_path, inputs):
         outs.append(np.fromfile(tmp_path / "output" / f"scenario_{ens}", dtype="<f4"))
     assert os.path.getsize(tmp_path / "output" / "flux_cache") == (3 * 730 + 5) * 96 * 48 * 4
     assert outs[0].size == 96 * 48 * 5 * 12 and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("log_exp", [10, 8, 14])
+def test_original_variant_host(tmp_path, inputs, log_exp):
+    """greb_host_original: the upstream variant's shell (namelist_original, output/control + output/scenario) on the
+    engine, against that variant's own output files for the same experiment (tests/golden/logexp_g96.npz)."""
+    from greb_climate_model_amd import build, workload
+    host = os.path.join(build.PKG, "greb_host_original")
+    if not os.path.exists(host):
+        pytest.skip("greb_host_original not built (no Fortran compiler at build time)")
+    g = load_golden("logexp_g96.npz")
+    inputs.write_input_dir(str(tmp_path / "input"))
+    os.makedirs(tmp_path / "output")
+    with open(tmp_path / "namelist_original", "w") as f:
+        f.write(f"&NUMERICS\ntime_flux = 1\ntime_ctrl = 1\ntime_scnr = 2\n/\n&PHYSICS\n log_exp = {log_exp}\n/\n")
+    r = subprocess.run([host], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "% SCENARIO EXP:" in r.stdout and "% CONTROL RUN CO2=" in r.stdout
+    k = f"le{log_exp:02d}"
+    scen = workload.read_greb(str(tmp_path / "output" / "scenario"))
+    assert scen.shape == (24, 5, 48, 96)
+    raw = np.fromfile(tmp_path / "output" / "control", dtype="<f4")
+    assert raw.size == 730 * 96 * 48  # 730 TF_correct records, the first 60 overwritten by the control run
+    ctrl = raw[: 60 * 96 * 48].reshape(12, 5, 48, 96)
+    for i, tol in enumerate((1e-4, 1e-4, 1e-4, 2e-8, 1e-6)):
+        assert rms(scen[-1, i], g[k + "_scen_last"][i]) < tol, (log_exp, i)
+        assert rms(ctrl[-1, i], g[k + "_ctrl_last"][i]) < tol, (log_exp, i)
+        assert np.abs(scen[:, i].astype(np.float64).mean((1, 2)) - g[k + "_scen_stats"][:, i, 0]).max() < 3 * tol
