@@ -18,14 +18,16 @@
 // (Tair,q) register pair (greb_pair.h): both tracers share the winds, the sign split, the address
 // arithmetic and the row constants.
 //
-// Work distribution per sub-step (measured on MI355X: the loop is bound by VALU issue, ~1 ns per
-// wave-instruction per SIMD under load, so the lever is equal work per SIMD and full lanes):
-//   a TASK is one pair-quad of one row: 4 longitudes x (Tair,q).  The 46 non-polar rows give 432
-//   "sub" tasks (rows 1-9, 38-46: sub-cycled formulas, one sweep) and 672 "full" tasks (rows 10-37).
-//   A PASS is 64 consecutive tasks of one class, one per lane: 7 sub + 11 full passes, dealt
-//   statically to waves 0-5, three each, so no wave ever executes both stencil families.
-//   waves 6-7: the polar rows 0 / 47 (8 dependent Jacobi sweeps per diffusion call,
-//   src/greb.f90:656-717): 48 lanes x 2 longitudes x (Tair,q), neighbours through an LDS row buffer.
+// Work distribution per sub-step (measured on MI355X: the bulk is the critical path, bound by VALU issue on the
+// busiest SIMD and by LDS bandwidth; a wave issues at most ~1 instruction per 4.5 cycles, a SIMD ~1 per 3):
+//   a TASK works on pair-quads: 4 longitudes x (Tair,q) of one row, or of two vertically stacked rows that share
+//   the six rows of their column (44 instead of 62 ds_read_b128).  The 46 non-polar rows are the "sub" family
+//   (rows 1-9, 38-46: sub-cycled formulas, one sweep) and the "full" family (rows 10-37).  A PASS is 64 tasks of
+//   one kind, one per lane; FAST: 3 passes of sub row-pairs, 3 of full row-pairs, 1 + 4.5 of single rows,
+//   STRICT: 7 + 11 single-row passes; dealt statically to six bulk waves (see "FAST schedule" / pass_of) with
+//   each lane's task addresses computed once per launch.
+//   two polar waves: rows 0 / 47 (8 dependent Jacobi sweeps per diffusion call, src/greb.f90:656-717):
+//   48 lanes x 2 longitudes x (Tair,q), neighbours through an LDS row buffer.
 // One s_barrier per sub-step.
 #include <cstdlib>
 
