@@ -53,6 +53,16 @@ __device__ __forceinline__ void st4(float* p, const f4& a) {
   vfloat4 v; v.x = a.v[0]; v.y = a.v[1]; v.z = a.v[2]; v.w = a.v[3];
   *reinterpret_cast<vfloat4*>(p) = v;
 }
+// streaming (non-temporal) forms for data touched once per launch: they do not displace the L2 / MALL lines of
+// the other stream
+__device__ __forceinline__ f4 ld4_nt(const float* p) {
+  const vfloat4 a = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(p));
+  return f4{{a.x, a.y, a.z, a.w}};
+}
+__device__ __forceinline__ void st4_nt(float* p, const f4& a) {
+  vfloat4 v; v.x = a.v[0]; v.y = a.v[1]; v.z = a.v[2]; v.w = a.v[3];
+  __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(p));
+}
 __device__ __forceinline__ void st4(lfloat* p, const f4& a) {
   vfloat4 v; v.x = a.v[0]; v.y = a.v[1]; v.z = a.v[2]; v.w = a.v[3];
   *(__attribute__((address_space(3))) vfloat4*)p = v;

@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
 //     dependent Jacobi sweeps each (src/greb.f90:656-717);
 //   * the compute phase issues no global load (row constants are staged in LDS): s_waitcnt vmcnt
 //     is in-order, one table load would wait for the whole prefetch.
+//   * loads and stores are non-temporal (each byte is touched once per launch): measured 5.1-5.2 -> 5.6 TB/s,
+//     above the box's torch copy rate.
 // Traffic = the algorithmic 12 B/point exactly (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE).
 // ---------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 256;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(kStreamThreads) void diffusion_stream_kernel(const 
 #pragma unroll
     for (int j = 0; j < kStreamQPT; ++j) {
       const int i = tid + j * kStreamThreads;
-      if (i < nquad) { rT[j] = ld4(T1 + fo + 4 * i); rW[j] = ld4(wz + fo + 4 * i); }
+      if (i < nquad) { rT[j] = ld4_nt(T1 + fo + 4 * i); rW[j] = ld4_nt(wz + fo + 4 * i); }
     }
   }
   // static role data
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(kStreamThreads) void diffusion_stream_kernel(const 
 #pragma unroll
       for (int j = 0; j < kStreamQPT; ++j) {
         const int i = tid + j * kStreamThreads;
-        if (i < nquad) { rT[j] = ld4(T1 + fo + 4 * i); rW[j] = ld4(wz + fo + 4 * i); }
+        if (i < nquad) { rT[j] = ld4_nt(T1 + fo + 4 * i); rW[j] = ld4_nt(wz + fo + 4 * i); }
       }
     }
     float* out = dX + (size_t)b * nx * ny;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(kStreamThreads) void diffusion_stream_kernel(const 
           in.Tm2 = CT[1]; in.Tp2 = CT[1]; in.wm2 = zero4(); in.wp2 = zero4();
           float o[4];
           dif_quad<STRICT>(in, rk, k, ny, o);
-          st4(out + (size_t)k * nx + 4 * tq, f4{{o[0], o[1], o[2], o[3]}});
+          st4_nt(out + (size_t)k * nx + 4 * tq, f4{{o[0], o[1], o[2], o[3]}});
         }
         CT[0] = CT[1]; CW[0] = CW[1]; CT[1] = CT[2]; CW[1] = CW[2];
       }

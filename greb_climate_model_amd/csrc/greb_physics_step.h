@@ -125,7 +125,8 @@ __device__ __forceinline__ void physics_quad(const MemberArgs& a, const Phys& P,
         for (int e = 0; e < 4; ++e) {
           r0.v[e] = s0.v[e] / ndm; r1.v[e] = s1.v[e] / ndm; r2.v[e] = s2.v[e] / ndm; r3.v[e] = s3.v[e] / ndm; r4.v[e] = s4.v[e] / ndm;
         }
-        st4(rec + p0, r0); st4(rec + np + p0, r1); st4(rec + 2 * np + p0, r2); st4(rec + 3 * np + p0, r3); st4(rec + 4 * np + p0, r4);
+        // written once, read by nobody on the device: keep the records out of the L2 / MALL the state lives in
+        st4_nt(rec + p0, r0); st4_nt(rec + np + p0, r1); st4_nt(rec + 2 * np + p0, r2); st4_nt(rec + 3 * np + p0, r3); st4_nt(rec + 4 * np + p0, r4);
         s0 = s1 = s2 = s3 = s4 = zero4();
       }
       st4(acc + p0, s0); st4(acc + np + p0, s1); st4(acc + 2 * np + p0, s2); st4(acc + 3 * np + p0, s3); st4(acc + 4 * np + p0, s4);
