@@ -250,3 +250,34 @@ def test_engine_g384_vs_oracle(eng_mod, oracle_lib):
     assert np.abs(yf[1] - yfo).max() < 2e-3 and np.abs(yr[1] - yro).max() < 2e-3
     assert rms(mon[0, 0, 11, 0], mon[1, 0, 11, 0]) > 1e-2  # the members differ (CO2)
     o.close(); e.close()
+
+
+# ------------------------------------------------------------------------------------ error behaviour
+def test_bad_arguments_are_errors_with_messages(eng_mod, params, inputs):
+    """Nothing throws or exits across the ABI: bad shapes / indices / call arguments come back as GREB_E_INVALID
+    with a message (include/greb_engine.h error convention); zero flux-correction years are legal (A.9-10)."""
+    import ctypes as C
+    from greb_climate_model_amd import abi, workload
+    L = eng_mod.lib()
+    fields, keep = abi.make_fields(inputs)
+    h = C.c_void_p()
+    for nx, ny, nm in ((94, 48, 1), (96, 3, 1), (96, 48, 0), (8, 48, 1)):
+        assert L.greb_engine_create(C.byref(params), nx, ny, C.byref(fields), nm, None, 0, 0, C.byref(h)) == -1
+        assert b"bad argument" in L.greb_engine_last_error(None)
+    p2 = abi.default_params(ipx=97, ipy=1)
+    assert L.greb_engine_create(C.byref(p2), 96, 48, C.byref(fields), 1, None, 0, 0, C.byref(h)) == -1
+    assert L.greb_engine_create(C.byref(params), 96, 48, C.byref(fields), 1, None, 99, 0, C.byref(h)) != 0  # no such device
+    e = eng_mod.Engine(inputs, params, n_members=2)
+    with pytest.raises(eng_mod.GrebError):
+        e.state(2)
+    with pytest.raises(eng_mod.GrebError):
+        e.set_experiment(1 << 9)
+    with pytest.raises(eng_mod.GrebError):
+        e.point_physics(731, 680.0, np.zeros((5, 48, 96), np.float32))
+    assert L.greb_engine_run(e.h, 0, None, None, None, 0) == -1
+    assert e.flux_correction(0).shape == (2, 0, 2)  # time_flux = 0: corrections stay zero, the run still works
+    mon, _ = e.run(1, 680.0)
+    assert np.isfinite(mon).all()
+    e.close()
+    with pytest.raises(eng_mod.GrebError):  # batched routines: same validation
+        eng_mod.diffusion(np.zeros((48, 94), np.float32), np.ones((48, 94), np.float32), params)
