@@ -33,7 +33,11 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
   const int b = blockIdx.x;
   const RowTables& tab = tabp[tab_index ? tab_index[b / tab_div] : 0];
   const int nq = nx >> 2;
-  const int k0 = blockIdx.y * rows_per_band;
+  // bands are handed out from the poles inwards (0, last, 1, last-1, ...): the polar bands carry the long Jacobi
+  // chains, so they must start first or they become the tail of the launch
+  const int nbands = gridDim.y;
+  const int band = (blockIdx.y & 1) ? nbands - 1 - (blockIdx.y >> 1) : (blockIdx.y >> 1);
+  const int k0 = band * rows_per_band;
   const int k1 = min(ny, k0 + rows_per_band);
   constexpr int halo = MODE == kChainDif ? 1 : 2;
   const int r0 = max(0, k0 - halo), r1 = min(ny, k1 + halo);
