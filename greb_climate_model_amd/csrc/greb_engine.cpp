@@ -362,13 +362,13 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
 
 int greb_engine_destroy(greb_engine* e) {
   if (!e) return 0;
-  hipSetDevice(e->device);
+  (void)hipSetDevice(e->device); // teardown: nothing useful to do with an error here
   void* ptrs[] = {e->z_topo, e->glacier, e->sw_solar, e->tclim, e->qclim, e->uclim, e->vclim, e->mldclim,
                   e->cldclim, e->swetclim, e->toclim, e->z_ocean, e->wz_air, e->wz_vapor, e->state, e->acc,
                   e->corr, e->corr_index, e->tab_index, e->tabs, e->phys, e->co2_dev, e->monthly_dev, e->yearly_dev,
                   e->Xa, e->Xb, e->red, e->W2};
-  for (void* q : ptrs) if (q) hipFree(q);
-  if (e->stream) hipStreamDestroy(e->stream);
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return 0;
 }
@@ -509,7 +509,7 @@ int greb_engine_set_state(greb_engine* e, int member, const float* state5) {
 namespace {
 struct DevBuf {
   float* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
 };
 int batched_common(const greb_params* p, int nx, int ny, int batch, int device) {
   if (!p || nx < 12 || (nx & 3) || ny < 5 || ny > kMaxNy || batch < 1) return fail(nullptr, GREB_E_INVALID, "batched: bad argument");
