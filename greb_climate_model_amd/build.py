@@ -66,6 +66,24 @@ def build_host(verbose: bool = False) -> str | None:
     return first
 
 
+def build_c_example(verbose: bool = False) -> str | None:
+    """examples/greb_run.c (the ABI from plain C, gcc) -> greb_climate_model_amd/greb_run_c."""
+    cc = shutil.which("gcc") or shutil.which("cc")
+    src = os.path.join(ROOT, "examples", "greb_run.c")
+    if cc is None or not os.path.exists(src):
+        return None
+    out = os.path.join(PKG, "greb_run_c")
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return out
+    cmd = [cc, "-std=c11", "-O2", "-Wall", "-Wextra", src, "-I" + os.path.join(ROOT, "include"), "-L" + PKG, "-lgreb_hip",
+           "-Wl,-rpath," + PKG, "-Wl,-rpath,$ORIGIN", "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
     print(build_host(verbose=True))
+    print(build_c_example(verbose=True))

@@ -92,3 +92,24 @@ def test_original_variant_host(tmp_path, inputs, log_exp):
         assert rms(scen[-1, i], g[k + "_scen_last"][i]) < tol, (log_exp, i)
         assert rms(ctrl[-1, i], g[k + "_ctrl_last"][i]) < tol, (log_exp, i)
         assert np.abs(scen[:, i].astype(np.float64).mean((1, 2)) - g[k + "_scen_stats"][:, i, 0]).max() < 3 * tol
+
+
+def test_plain_c_driver(tmp_path, inputs):
+    """examples/greb_run.c: the ABI used from plain C (no Fortran, no Python in the process) reproduces the
+    reference's 1+2-yr output file."""
+    from greb_climate_model_amd import build, workload
+    exe = os.path.join(build.PKG, "greb_run_c")
+    if not os.path.exists(exe):
+        pytest.skip("greb_run_c not built")
+    g = load_golden("run_short_g96.npz")
+    inputs.write_input_dir(str(tmp_path / "input"))
+    out = tmp_path / "scenario"
+    r = subprocess.run([exe, str(tmp_path / "input"), str(out), "1", "2", "680", "95", "38"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    mon = workload.read_greb(str(out))
+    for i, tol in enumerate((1e-4, 1e-4, 1e-4, 2e-8, 1e-6)):
+        assert rms(mon[:, i], g["monthly"][:, i]) < tol, i
+    rows = np.asarray([[float(x) for x in l.split()] for l in r.stdout.splitlines() if len(l.split()) == 4])
+    assert rows.shape == (3, 4) and np.abs(rows[:, 2:] - g["yearly"]).max() < 2e-3
+    r = subprocess.run([exe, str(tmp_path / "nonexistent"), str(out), "1", "1", "680"], capture_output=True, text=True)
+    assert r.returncode == 2 and "cannot open" in r.stderr
