@@ -87,6 +87,20 @@ __device__ __forceinline__ float split_p(float u) { return u >= 0.0f ? 0.0f : u;
 // STRICT pieces (reference expression order)
 // ============================================================================================
 
+// IEEE x/20 and x/3 in three instructions instead of the ~10 of the generic division sequence:
+//   q = x*r,  e = fma(-q, c, x),  result = fma(e, r, q)      with r = RN(1/c)
+// Checked EXHAUSTIVELY on the CPU against x/c for all 2^32 operands: identical for every x whose quotient is a
+// normal number; the only differences are in the subnormal range (|x| < 4.8e-38 for c = 20) and the sign of an
+// exact zero quotient (-0 comes out +0) -- neither changes any value the model compares or prints.
+__device__ __forceinline__ float div_by_const(float x, float c, float r) {
+#pragma clang fp contract(off)
+  const float q = x * r;
+  const float e = __builtin_fmaf(-q, c, x);
+  return __builtin_fmaf(e, r, q);
+}
+__device__ __forceinline__ float div20(float x) { return div_by_const(x, 20.f, 1.0f / 20.f); }
+__device__ __forceinline__ float div3(float x) { return div_by_const(x, 3.f, 1.0f / 3.f); }
+
 // 7-point sum of src/greb.f90:595-600 for window index c (4..7)
 __device__ __forceinline__ float dif_S_strict(const float* T, const float* w, int c) {
 #pragma clang fp contract(off)
@@ -101,7 +115,7 @@ __device__ __forceinline__ float dif_S_strict(const float* T, const float* w, in
 __device__ __forceinline__ void dif_lon_strict(const float T[12], const float w[12], float cc, float d[4]) {
 #pragma clang fp contract(off)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) d[i] = cc * dif_S_strict(T, w, 4 + i) / 20.f;
+  for (int i = 0; i < 4; ++i) d[i] = div20(cc * dif_S_strict(T, w, 4 + i));
 }
 
 // src/greb.f90:802-806: full-row advection, window index c
@@ -111,9 +125,8 @@ __device__ __forceinline__ void adv_lon_full_strict(const float T[12], const flo
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = 4 + i;
-    d[i] = ccx * (-split_m(u[i]) * (w[c - 1] * (T[c] - T[c - 1]) + w[c - 2] * (T[c] - T[c - 2]))
-                  + split_p(u[i]) * (w[c + 1] * (T[c] - T[c + 1]) + w[c + 2] * (T[c] - T[c + 2])))
-           / 3.f;
+    d[i] = div3(ccx * (-split_m(u[i]) * (w[c - 1] * (T[c] - T[c - 1]) + w[c - 2] * (T[c] - T[c - 2]))
+                  + split_p(u[i]) * (w[c + 1] * (T[c] - T[c + 1]) + w[c + 2] * (T[c] - T[c + 2]))));
   }
 }
 
@@ -124,13 +137,12 @@ __device__ __forceinline__ float adv_lon_sub_point_strict(const float* T, const 
                                                           int c, bool bug) {
 #pragma clang fp contract(off)
   const int p1 = c + 1, p2 = bug ? c + 1 : c + 2, p3 = c + 3;
-  return ccx2 * (-split_m(u) * (10.f * w[c - 1] * (T[c] - T[c - 1])
+  return div20(ccx2 * (-split_m(u) * (10.f * w[c - 1] * (T[c] - T[c - 1])
                                 + 4.f * w[c - 2] * (T[c - 1] - T[c - 2])
                                 + w[c - 3] * (T[c - 2] - T[c - 3]))
                  + split_p(u) * (10.f * w[p1] * (T[c] - T[p1])
                                  + 4.f * w[p2] * (T[p1] - T[p2])
-                                 + w[p3] * (T[p2] - T[p3])))
-         / 20.f;
+                                 + w[p3] * (T[p2] - T[p3]))));
 }
 __device__ __forceinline__ void adv_lon_sub_strict(const float T[12], const float w[12], const float u[4],
                                                    float ccx2, bool last_quad, float d[4]) {
@@ -172,11 +184,11 @@ __device__ __forceinline__ void adv_lat_strict(const f4& T0, const f4& Tm2, cons
     const float dm1 = wm1.v[i] * (t0 - Tm1.v[i]), dm2 = wm2.v[i] * (t0 - Tm2.v[i]);
     const float dp1 = wp1.v[i] * (t0 - Tp1.v[i]), dp2 = wp2.v[i] * (t0 - Tp2.v[i]);
     float r;
-    if (k == 0) r = ccy * (vp * (dp1 + dp2)) / 3.f;                              // :759-761
-    else if (k == 1) r = ccy * (-vm * (dm1) + vp * (dp1 + dp2) / 3.f);           // :766-769
-    else if (k <= ny - 3) r = ccy * (-vm * (dm1 + dm2) + vp * (dp1 + dp2)) / 3.f; // :774-778
-    else if (k == ny - 2) r = ccy * (-vm * (dm1 + dm2) / 3.f + vp * (dp1));      // :784-787
-    else r = ccy * (-vm * (dm1 + dm2)) / 3.f;                                    // :792-794
+    if (k == 0) r = div3(ccy * (vp * (dp1 + dp2)));                              // :759-761
+    else if (k == 1) r = ccy * (-vm * (dm1) + div3(vp * (dp1 + dp2)));           // :766-769
+    else if (k <= ny - 3) r = div3(ccy * (-vm * (dm1 + dm2) + vp * (dp1 + dp2))); // :774-778
+    else if (k == ny - 2) r = ccy * (div3(-vm * (dm1 + dm2)) + vp * (dp1));      // :784-787
+    else r = div3(ccy * (-vm * (dm1 + dm2)));                                    // :792-794
     d[i] = r;
   }
 }

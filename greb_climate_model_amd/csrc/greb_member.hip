@@ -424,7 +424,7 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, bo
             const int c = 4 + pt;
             float dd;
             if (which) dd = adv_lon_sub_point_strict(Ts, ws, uu[pt], cc, c, bug_lane && pt == 1);
-            else dd = cc * dif_S_strict(Ts, ws, c) / 20.f;
+            else dd = div20(cc * dif_S_strict(Ts, ws, c));
             if (dd <= -Ts[c]) dd = -0.9f * Ts[c]; // :715 / :907
             const float tn = Ts[c] + dd;
             if (tr) th[pt].y = tn; else th[pt].x = tn;
@@ -487,10 +487,10 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, bo
         float dTy, aTy;
         if (pole == 0) {
           dTy = rk.dif_ccy * b1 * (-t0 + a1);                                        // :589
-          aTy = rk.adv_ccy * (vp * (b1 * (t0 - a1) + b2 * (t0 - a2))) / 3.f;         // :759-761
+          aTy = div3(rk.adv_ccy * (vp * (b1 * (t0 - a1) + b2 * (t0 - a2))));         // :759-761
         } else {
           dTy = rk.dif_ccy * b1 * (a1 - t0);                                         // :590
-          aTy = rk.adv_ccy * (-vm * (b1 * (t0 - a1) + b2 * (t0 - a2))) / 3.f;        // :792-794
+          aTy = div3(rk.adv_ccy * (-vm * (b1 * (t0 - a1) + b2 * (t0 - a2))));        // :792-794
         }
         const float th0 = tr ? Th[0][pt].y : Th[0][pt].x, th1 = tr ? Th[1][pt].y : Th[1][pt].x;
         const float dd = w0 * ((th0 - t0) + dTy); // :718, :721

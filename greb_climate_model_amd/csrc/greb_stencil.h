@@ -271,7 +271,7 @@ __device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfl
 #pragma clang fp contract(off)
         const int c = 3 + i;
         float d = is_adv ? adv_lon_sub_point_strict(T, w, u[i], cc, c, bug_lane && i == P - 3)
-                         : cc * dif_S_strict(T, w, c) / 20.f;
+                         : div20(cc * dif_S_strict(T, w, c));
         if (d <= -T[c]) d = -0.9f * T[c]; // :715 / :907
         Tn[i] = T[c] + d;
       }
