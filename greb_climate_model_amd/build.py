@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libgreb_hip.so")
-SOURCES = ["greb_engine.cpp", "greb_kernels.hip", "greb_member.hip", "greb_ensemble.hip"]
+SOURCES = ["greb_engine.cpp", "greb_kernels.hip", "greb_member.hip", "greb_ensemble.hip", "greb_pair_sweep.hip"]
 HEADERS = ["greb_device.h", "greb_kernels.h", "greb_stencil.h", "greb_pair.h", "greb_physics_step.h", os.path.join(ROOT, "include", "greb_engine.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                "-I" + os.path.join(ROOT, "include")]

@@ -106,6 +106,8 @@ struct greb_engine {
   bool shared_corr = true; // all members share physics -> one flux-correction set
   bool fused = true;       // every member has the 96x48 default sub-cycling layout -> fused member kernel
   float *Xa = nullptr, *Xb = nullptr, *red = nullptr, *W2 = nullptr; // any-grid (multi-launch) engine work arrays
+  float* W2p = nullptr; // [np][{wz_air,wz_vapor}] for the pair form of the sub-step (FAST, 384-wide grids)
+  bool pairs = false;
   hipStream_t stream = nullptr;
   // device
   float *z_topo = nullptr, *glacier = nullptr, *sw_solar = nullptr;
@@ -176,20 +178,31 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     return 0;
   }
   const size_t np = (size_t)e->np;
-  HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
+  // FAST on a 384-wide grid: both tracers of a member as pairs (greb_pair_sweep.hip); the experiment that diffuses
+  // but does not advect vapour needs per-tracer winds and takes the scalar kernel
+  // Packed arithmetic issues more slowly per instruction, so the pair kernel's polar chains take 71 us per launch
+  // against the scalar kernel's 43 us: below ~40 members the launch is bound by that latency and the scalar kernel
+  // wins (1.31 vs 0.80 yr/s for one member, 29 vs 24 member-yr/s at 32); above it the pair kernel's instruction
+  // count does (47 vs 29 at 64 members, 54 at 128).
+  const bool pairs = e->pairs && nrun >= 40 && !(e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY);
+  if (pairs) HIP_TRY(e, launch_pack_pairs(e->state, e->Xa, e->np, nrun, e->stream));
+  else HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
   for (int s = 0; s < kNT; ++s) {
     const long long it = a.it0 + s;
     const int ityr = (int)((it - 1) % kNT) + 1;
     const size_t off = (size_t)(ityr - 1) * np;
     float *cur = e->Xa, *nxt = e->Xb;
     for (int tt = 0; tt < a.nsub; ++tt) {
-      HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
-                                      e->ny, nrun, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
+      if (pairs)
+        HIP_TRY(e, launch_substep_pairs(cur, e->W2p, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->ny, nrun, e->stream));
+      else
+        HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
+                                        e->ny, nrun, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
       float* t = cur; cur = nxt; nxt = t;
     }
     MemberArgs b = a;
     b.it0 = it; b.nsteps = 1; // the step kernel derives its clock from it0; year indices are those of `a`
-    HIP_TRY(e, launch_physics_step(b, cur, e->Xa, e->red, nrun, e->strict, e->stream));
+    HIP_TRY(e, launch_physics_step(b, cur, e->Xa, e->red, nrun, e->strict, e->stream, pairs));
     if (ityr == kNT && a.yearly)
       HIP_TRY(e, launch_yearly(e->red, a.yearly, e->np, e->nx, a.ipx, a.ipy, a.yearly_years, a.yearly_year0, nrun, e->strict, e->stream));
   }
@@ -356,6 +369,13 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
     HIP_TRY(e, dev_alloc(&e->W2, 2 * np));
     HIP_TRY(e, hipMemcpy(e->W2, wz_air.data(), np * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->W2 + np, wz_vapor.data(), np * sizeof(float), hipMemcpyHostToDevice));
+    e->pairs = !e->strict && pair_sweep_supported(nx, ny);
+    if (e->pairs) {
+      std::vector<float> w2p(2 * np);
+      for (size_t i = 0; i < np; ++i) { w2p[2 * i] = wz_air[i]; w2p[2 * i + 1] = wz_vapor[i]; }
+      HIP_TRY(e, dev_alloc(&e->W2p, 2 * np));
+      HIP_TRY(e, hipMemcpy(e->W2p, w2p.data(), 2 * np * sizeof(float), hipMemcpyHostToDevice));
+    }
   }
   return 0;
 }
@@ -366,7 +386,7 @@ int greb_engine_destroy(greb_engine* e) {
   void* ptrs[] = {e->z_topo, e->glacier, e->sw_solar, e->tclim, e->qclim, e->uclim, e->vclim, e->mldclim,
                   e->cldclim, e->swetclim, e->toclim, e->z_ocean, e->wz_air, e->wz_vapor, e->state, e->acc,
                   e->corr, e->corr_index, e->tab_index, e->tabs, e->phys, e->co2_dev, e->monthly_dev, e->yearly_dev,
-                  e->Xa, e->Xb, e->red, e->W2};
+                  e->Xa, e->Xb, e->red, e->W2, e->W2p};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;

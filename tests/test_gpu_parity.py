@@ -234,22 +234,29 @@ def test_multilaunch_engine_g96_vs_reference(eng_mod, params, inputs, strict):
 
 def test_engine_g384_vs_oracle(eng_mod, oracle_lib):
     """BASELINE config 3's grid: 384x192 (bilinear-upsampled inputs), 1 flux-correction year + 1
-    scenario year, STRICT, 2 members (CO2 340 / 680) against the oracle at the same grid.  Every row
+    scenario year, 2 members (CO2 340 / 680) against the oracle at the same grid, in STRICT arithmetic (scalar
+    any-grid kernel) and in FAST arithmetic (the (Tair,q)-pair kernel of greb_pair_sweep.hip).  Every row
     is sub-cycled (up to 225 sweeps); the two polar rows keep the reference's inherited
     time2 = 1, ccx2 = 0 behaviour."""
     from greb_climate_model_amd import abi, workload
     inp = workload.make_inputs(384, 192)
     p = abi.default_params(ipx=380, ipy=150)
-    e = eng_mod.Engine(inp, p, n_members=2, strict=True)
-    yf = e.flux_correction(1)
-    mon, yr = e.run(1, np.asarray([[340.0], [680.0]], np.float32))
     o = oracle_lib.Oracle(inp, p)
     yfo = o.flux_correction(1)
     ref, yro = o.run(1, 680.0)
-    _check_run(mon[1, 0], ref[0], "g384")
-    assert np.abs(yf[1] - yfo).max() < 2e-3 and np.abs(yr[1] - yro).max() < 2e-3
-    assert rms(mon[0, 0, 11, 0], mon[1, 0, 11, 0]) > 1e-2  # the members differ (CO2)
-    o.close(); e.close()
+    o.close()
+    # 2 members: scalar kernel; 40 members (the engine's threshold for the pair kernel): member 39 carries 680 ppm
+    for strict, nm in ((True, 2), (False, 2), (False, 40)):
+        e = eng_mod.Engine(inp, p, n_members=nm, strict=strict)
+        yf = e.flux_correction(1)
+        co2 = np.full((nm, 1), 340.0, np.float32); co2[-1] = 680.0
+        mon, yr = e.run(1, co2)
+        e.close()
+        _check_run(mon[-1, 0], ref[0], f"g384 strict={strict} members={nm}")
+        assert np.abs(yf[-1] - yfo).max() < 2e-3 and np.abs(yr[-1] - yro).max() < 2e-3
+        assert rms(mon[0, 0, 11, 0], mon[-1, 0, 11, 0]) > 1e-2  # the members differ (CO2)
+        if nm > 2:
+            assert np.array_equal(mon[0], mon[1])  # replicas agree bit for bit
 
 
 # ------------------------------------------------------------------------------------ error behaviour
