@@ -87,22 +87,39 @@ __device__ __forceinline__ float split_p(float u) { return u >= 0.0f ? 0.0f : u;
 // STRICT pieces (reference expression order)
 // ============================================================================================
 
+// (Tair, q) pair: the STRICT pieces below are written once for an element type E = float (one field) or v2 (both
+// transported tracers at once).  With contraction off every v2 operation is the same IEEE operation on each half
+// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 only where an fma is written), so the packed form is bit-identical.
+typedef float v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fma_e(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ v2 fma_e(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float splat_e(float x, float) { return x; }
+__device__ __forceinline__ v2 splat_e(float x, v2) { return v2{x, x}; }
+// the sub-cycle clamp `where(dTxh <= -T1h) dTxh = -0.9*T1h` (:715, :907), per element
+__device__ __forceinline__ float clamp_e(float d, float T) {
+#pragma clang fp contract(off)
+  return (d <= -T) ? -0.9f * T : d;
+}
+__device__ __forceinline__ v2 clamp_e(v2 d, v2 T) { return v2{clamp_e(d.x, T.x), clamp_e(d.y, T.y)}; }
+
 // IEEE x/20 and x/3 in three instructions instead of the ~10 of the generic division sequence:
 //   q = x*r,  e = fma(-q, c, x),  result = fma(e, r, q)      with r = RN(1/c)
 // Checked EXHAUSTIVELY on the CPU against x/c for all 2^32 operands: identical for every x whose quotient is a
 // normal number; the only differences are in the subnormal range (|x| < 4.8e-38 for c = 20) and the sign of an
 // exact zero quotient (-0 comes out +0) -- neither changes any value the model compares or prints.
-__device__ __forceinline__ float div_by_const(float x, float c, float r) {
+template <typename E>
+__device__ __forceinline__ E div_by_const(E x, float c, float r) {
 #pragma clang fp contract(off)
-  const float q = x * r;
-  const float e = __builtin_fmaf(-q, c, x);
-  return __builtin_fmaf(e, r, q);
+  const E q = x * r;
+  const E e = fma_e(-q, splat_e(c, x), x);
+  return fma_e(e, splat_e(r, x), q);
 }
-__device__ __forceinline__ float div20(float x) { return div_by_const(x, 20.f, 1.0f / 20.f); }
-__device__ __forceinline__ float div3(float x) { return div_by_const(x, 3.f, 1.0f / 3.f); }
+template <typename E> __device__ __forceinline__ E div20(E x) { return div_by_const(x, 20.f, 1.0f / 20.f); }
+template <typename E> __device__ __forceinline__ E div3(E x) { return div_by_const(x, 3.f, 1.0f / 3.f); }
 
 // 7-point sum of src/greb.f90:595-600 for window index c (4..7)
-__device__ __forceinline__ float dif_S_strict(const float* T, const float* w, int c) {
+template <typename E>
+__device__ __forceinline__ E dif_S_strict(const E* T, const E* w, int c) {
 #pragma clang fp contract(off)
   return 10.f * (w[c - 1] * (T[c - 1] - T[c]) + w[c + 1] * (T[c + 1] - T[c]))
          + 4.f * (w[c - 2] * (T[c - 2] - T[c - 1]) + w[c - 1] * (T[c] - T[c - 1]))
@@ -112,15 +129,17 @@ __device__ __forceinline__ float dif_S_strict(const float* T, const float* w, in
 }
 
 // one longitudinal diffusion increment: cc*S/20  (:595-600 with ccx, :659-664 with ccx2)
-__device__ __forceinline__ void dif_lon_strict(const float T[12], const float w[12], float cc, float d[4]) {
+template <typename E>
+__device__ __forceinline__ void dif_lon_strict(const E T[12], const E w[12], float cc, E d[4]) {
 #pragma clang fp contract(off)
 #pragma unroll
   for (int i = 0; i < 4; ++i) d[i] = div20(cc * dif_S_strict(T, w, 4 + i));
 }
 
 // src/greb.f90:802-806: full-row advection, window index c
-__device__ __forceinline__ void adv_lon_full_strict(const float T[12], const float w[12], const float u[4],
-                                                    float ccx, float d[4]) {
+template <typename E>
+__device__ __forceinline__ void adv_lon_full_strict(const E T[12], const E w[12], const float u[4],
+                                                    float ccx, E d[4]) {
 #pragma clang fp contract(off)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -133,8 +152,9 @@ __device__ __forceinline__ void adv_lon_full_strict(const float T[12], const flo
 // src/greb.f90:845-851 (+ the :881 index bug for j = xdim-2): sub-cycled advection increment of
 // the point at window index c; bug = this is longitude xdim-2 (1-based), whose "+2" neighbour
 // aliases the "+1" one (jp2 = xdim-1)
-__device__ __forceinline__ float adv_lon_sub_point_strict(const float* T, const float* w, float u, float ccx2,
-                                                          int c, bool bug) {
+template <typename E>
+__device__ __forceinline__ E adv_lon_sub_point_strict(const E* T, const E* w, float u, float ccx2,
+                                                      int c, bool bug) {
 #pragma clang fp contract(off)
   const int p1 = c + 1, p2 = bug ? c + 1 : c + 2, p3 = c + 3;
   return div20(ccx2 * (-split_m(u) * (10.f * w[c - 1] * (T[c] - T[c - 1])
@@ -144,25 +164,28 @@ __device__ __forceinline__ float adv_lon_sub_point_strict(const float* T, const 
                                  + 4.f * w[p2] * (T[p1] - T[p2])
                                  + w[p3] * (T[p2] - T[p3]))));
 }
-__device__ __forceinline__ void adv_lon_sub_strict(const float T[12], const float w[12], const float u[4],
-                                                   float ccx2, bool last_quad, float d[4]) {
+template <typename E>
+__device__ __forceinline__ void adv_lon_sub_strict(const E T[12], const E w[12], const float u[4],
+                                                   float ccx2, bool last_quad, E d[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) d[i] = adv_lon_sub_point_strict(T, w, u[i], ccx2, 4 + i, last_quad && i == 1);
 }
 
 // clamp + accumulate of the sub-cycle loops (:715-716, :907-908)
-__device__ __forceinline__ void clamp_add(float T1h[4], float d[4]) {
+template <typename E>
+__device__ __forceinline__ void clamp_add(E T1h[4], E d[4]) {
 #pragma clang fp contract(off)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (d[i] <= -T1h[i]) d[i] = -0.9f * T1h[i];
+    d[i] = clamp_e(d[i], T1h[i]);
     T1h[i] = T1h[i] + d[i];
   }
 }
 
 // latitudinal diffusion (:585-590).  Tm/Tp, wm/wp: rows k-1 / k+1 (ignored where absent)
-__device__ __forceinline__ void dif_lat_strict(const f4& T0, const f4& Tm, const f4& Tp, const f4& wm,
-                                               const f4& wp, float ccy, int k, int ny, float d[4]) {
+template <typename Q, typename E>
+__device__ __forceinline__ void dif_lat_strict(const Q& T0, const Q& Tm, const Q& Tp, const Q& wm,
+                                               const Q& wp, float ccy, int k, int ny, E d[4]) {
 #pragma clang fp contract(off)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -173,17 +196,19 @@ __device__ __forceinline__ void dif_lat_strict(const f4& T0, const f4& Tm, const
 }
 
 // latitudinal advection (:756-795).  T/w at rows k-2,k-1,k+1,k+2
-__device__ __forceinline__ void adv_lat_strict(const f4& T0, const f4& Tm2, const f4& Tm1, const f4& Tp1,
-                                               const f4& Tp2, const f4& wm2, const f4& wm1, const f4& wp1,
-                                               const f4& wp2, const float v[4], float ccy, int k, int ny,
-                                               float d[4]) {
+template <typename Q, typename E>
+__device__ __forceinline__ void adv_lat_strict(const Q& T0, const Q& Tm2, const Q& Tm1, const Q& Tp1,
+                                               const Q& Tp2, const Q& wm2, const Q& wm1, const Q& wp1,
+                                               const Q& wp2, const float v[4], float ccy, int k, int ny,
+                                               E d[4]) {
 #pragma clang fp contract(off)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float t0 = T0.v[i], vm = split_m(v[i]), vp = split_p(v[i]);
-    const float dm1 = wm1.v[i] * (t0 - Tm1.v[i]), dm2 = wm2.v[i] * (t0 - Tm2.v[i]);
-    const float dp1 = wp1.v[i] * (t0 - Tp1.v[i]), dp2 = wp2.v[i] * (t0 - Tp2.v[i]);
-    float r;
+    const E t0 = T0.v[i];
+    const float vm = split_m(v[i]), vp = split_p(v[i]);
+    const E dm1 = wm1.v[i] * (t0 - Tm1.v[i]), dm2 = wm2.v[i] * (t0 - Tm2.v[i]);
+    const E dp1 = wp1.v[i] * (t0 - Tp1.v[i]), dp2 = wp2.v[i] * (t0 - Tp2.v[i]);
+    E r;
     if (k == 0) r = div3(ccy * (vp * (dp1 + dp2)));                              // :759-761
     else if (k == 1) r = ccy * (-vm * (dm1) + div3(vp * (dp1 + dp2)));           // :766-769
     else if (k <= ny - 3) r = div3(ccy * (-vm * (dm1 + dm2) + vp * (dp1 + dp2))); // :774-778

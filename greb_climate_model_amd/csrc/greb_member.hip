@@ -153,29 +153,45 @@ __device__ __forceinline__ void row_task(lfloat* lds, int cur, const TaskAddr& t
     const q8 Wm1 = ld8(wr - RS, q), Wp1 = ld8(wr + RS, q);
     const q8 Wm2 = k >= 2 ? ld8(Wc + km2 * RS, q) : zero8();
     const q8 Wp2 = k <= NY - 3 ? ld8(Wc + kp2 * RS, q) : zero8();
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr) {
-      QuadIn in;
-      const f4 lt = comp(LT, tr), ct = comp(CT, tr), rt = comp(RT, tr);
-      const f4 lw = comp(LW, tr), cw = comp(CW, tr), rw = comp(RW, tr);
+    // both tracers packed: with contraction off every v2 operation is the reference's IEEE operation on each half
+    {
+#pragma clang fp contract(off)
+      v2 T[12], w[12];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        in.T[j] = lt.v[j]; in.T[4 + j] = ct.v[j]; in.T[8 + j] = rt.v[j];
-        in.w[j] = lw.v[j]; in.w[4 + j] = cw.v[j]; in.w[8 + j] = rw.v[j];
+        T[j] = LT.v[j]; T[4 + j] = CT.v[j]; T[8 + j] = RT.v[j];
+        w[j] = LW.v[j]; w[4 + j] = CW.v[j]; w[8 + j] = RW.v[j];
       }
-      in.T0 = ct; in.w0 = cw;
-      in.Tm2 = comp(Tm2, tr); in.Tm1 = comp(Tm1, tr); in.Tp1 = comp(Tp1, tr); in.Tp2 = comp(Tp2, tr);
-      in.wm2 = comp(Wm2, tr); in.wm1 = comp(Wm1, tr); in.wp1 = comp(Wp1, tr); in.wp2 = comp(Wp2, tr);
-      float dd[4], da[4];
-      dif_quad<true>(in, rk, k, NY, dd);
-      adv_quad<true>(in, xq.v, yq.v, rk, k, NY, q == NQ - 1, da); // raw winds
-      {
-#pragma clang fp contract(off)
+      v2 dTx[4], dTy[4], dd[4], da[4];
+      // diffusion (dif_quad<true>)
+      dif_lon_strict(T, w, rk.dif_cc, dTx);
+      if (rk.sub) {
+        v2 T1h[4] = {T[4], T[5], T[6], T[7]};
+        clamp_add(T1h, dTx);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float x = (calm_q && tr == 1) ? in.T[4 + i] + dd[i] : in.T[4 + i] + dd[i] + da[i]; // :549 (orig :562)
-          if (tr == 0) xn.v[i].x = x; else xn.v[i].y = x;
-        }
+        for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - T[4 + i]; // :718
+      }
+      dif_lat_strict(CT, Tm1, Tp1, Wm1, Wp1, rk.dif_ccy, k, NY, dTy);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dd[i] = CW.v[i] * (dTx[i] + dTy[i]); // :721
+      // advection (adv_quad<true>), raw winds
+      if (!rk.sub) {
+        adv_lon_full_strict(T, w, xq.v, rk.adv_cc, dTx);
+      } else {
+        v2 T1h[4] = {T[4], T[5], T[6], T[7]};
+        adv_lon_sub_strict(T, w, xq.v, rk.adv_cc, q == NQ - 1, dTx);
+        clamp_add(T1h, dTx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - T[4 + i]; // :910
+      }
+      adv_lat_strict(CT, Tm2, Tm1, Tp1, Tp2, Wm2, Wm1, Wp1, Wp2, yq.v, rk.adv_ccy, k, NY, dTy);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        da[i] = dTx[i] + dTy[i];                       // :913
+        const v2 xd = T[4 + i] + dd[i];
+        v2 x = xd + da[i];                             // :549
+        if (calm_q) x.y = xd.y;                        // orig :562: vapour diffused, not advected
+        xn.v[i] = x;
       }
     }
   } else {
@@ -414,21 +430,14 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, bo
       v2 d[2];
       if (STRICT) {
 #pragma unroll
-        for (int tr = 0; tr < 2; ++tr) {
-          float Ts[10], ws[10];
-#pragma unroll
-          for (int i = 0; i < 10; ++i) { Ts[i] = tr ? T[i].y : T[i].x; ws[i] = tr ? w[i].y : w[i].x; }
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt) {
+        for (int pt = 0; pt < 2; ++pt) {
 #pragma clang fp contract(off)
-            const int c = 4 + pt;
-            float dd;
-            if (which) dd = adv_lon_sub_point_strict(Ts, ws, uu[pt], cc, c, bug_lane && pt == 1);
-            else dd = div20(cc * dif_S_strict(Ts, ws, c));
-            if (dd <= -Ts[c]) dd = -0.9f * Ts[c]; // :715 / :907
-            const float tn = Ts[c] + dd;
-            if (tr) th[pt].y = tn; else th[pt].x = tn;
-          }
+          const int c = 4 + pt;
+          v2 dd;
+          if (which) dd = adv_lon_sub_point_strict(T, w, uu[pt], cc, c, bug_lane && pt == 1);
+          else dd = div20(cc * dif_S_strict(T, w, c));
+          dd = clamp_e(dd, T[c]); // :715 / :907
+          th[pt] = T[c] + dd;
         }
       } else {
         v2 e[8], Pp[8], Pm[8];
@@ -477,27 +486,23 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, bo
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt) {
     if (STRICT) {
-#pragma unroll
-      for (int tr = 0; tr < 2; ++tr) {
 #pragma clang fp contract(off)
-        const float t0 = tr ? own[pt].y : own[pt].x, w0 = tr ? w[4 + pt].y : w[4 + pt].x;
-        const float a1 = tr ? T1[pt].y : T1[pt].x, a2 = tr ? T2[pt].y : T2[pt].x;
-        const float b1 = tr ? W1[pt].y : W1[pt].x, b2 = tr ? W2[pt].y : W2[pt].x;
-        const float vm = split_m(vv[pt]), vp = split_p(vv[pt]);
-        float dTy, aTy;
-        if (pole == 0) {
-          dTy = rk.dif_ccy * b1 * (-t0 + a1);                                        // :589
-          aTy = div3(rk.adv_ccy * (vp * (b1 * (t0 - a1) + b2 * (t0 - a2))));         // :759-761
-        } else {
-          dTy = rk.dif_ccy * b1 * (a1 - t0);                                         // :590
-          aTy = div3(rk.adv_ccy * (-vm * (b1 * (t0 - a1) + b2 * (t0 - a2))));        // :792-794
-        }
-        const float th0 = tr ? Th[0][pt].y : Th[0][pt].x, th1 = tr ? Th[1][pt].y : Th[1][pt].x;
-        const float dd = w0 * ((th0 - t0) + dTy); // :718, :721
-        const float da = (th1 - t0) + aTy;        // :910, :913
-        const float x = (calm_q && tr == 1) ? t0 + dd : t0 + dd + da; // :549 (orig :562)
-        if (tr) xn[pt].y = x; else xn[pt].x = x;
+      const v2 t0 = own[pt], w0 = w[4 + pt], a1 = T1[pt], a2 = T2[pt], b1 = W1[pt], b2 = W2[pt];
+      const float vm = split_m(vv[pt]), vp = split_p(vv[pt]);
+      v2 dTy, aTy;
+      if (pole == 0) {
+        dTy = rk.dif_ccy * b1 * (-t0 + a1);                                        // :589
+        aTy = div3(rk.adv_ccy * (vp * (b1 * (t0 - a1) + b2 * (t0 - a2))));         // :759-761
+      } else {
+        dTy = rk.dif_ccy * b1 * (a1 - t0);                                         // :590
+        aTy = div3(rk.adv_ccy * (-vm * (b1 * (t0 - a1) + b2 * (t0 - a2))));        // :792-794
       }
+      const v2 dd = w0 * ((Th[0][pt] - t0) + dTy); // :718, :721
+      const v2 da = (Th[1][pt] - t0) + aTy;        // :910, :913
+      const v2 xd = t0 + dd;
+      v2 x = xd + da;                              // :549
+      if (calm_q) x.y = xd.y;                      // orig :562
+      xn[pt] = x;
     } else {
       const float third = rk.adv_ccy * (1.f / 3.f);
       // pole 0: only the v<0 part couples (rows 1,2); pole 1: only the v>=0 part (rows 46,45)

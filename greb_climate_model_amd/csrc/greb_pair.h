@@ -12,7 +12,7 @@
 
 namespace greb {
 
-typedef float v2 __attribute__((ext_vector_type(2)));
+// v2 = (Tair, q) register pair: typedef in greb_device.h
 
 // a quad of 4 longitudes x 2 tracers = 8 floats = two dwordx4.
 // LDS row layout [half][quad][4]: half 0 holds longitudes (4q, 4q+1), half 1 (4q+2, 4q+3), each as
