@@ -24,7 +24,7 @@
 //   the six rows of their column (44 instead of 62 ds_read_b128).  The 46 non-polar rows are the "sub" family
 //   (rows 1-9, 38-46: sub-cycled formulas, one sweep) and the "full" family (rows 10-37).  A PASS is 64 tasks of
 //   one kind, one per lane; FAST: 3 passes of sub row-pairs, 3 of full row-pairs, 1 + 4.5 of single rows,
-//   STRICT: 7 + 11 single-row passes; dealt statically to six bulk waves (see "FAST schedule" / pass_of) with
+//   in both arithmetic modes; dealt statically to six bulk waves (see "The schedule") with
 //   each lane's task addresses computed once per launch.
 //   two polar waves: rows 0 / 47 (8 dependent Jacobi sweeps per diffusion call, src/greb.f90:656-717):
 //   48 lanes x 2 longitudes x (Tair,q), neighbours through an LDS row buffer.
@@ -131,87 +131,99 @@ __device__ __forceinline__ void st8p(lfloat* o, const q8& xn) {
   *(__attribute__((address_space(3))) vfloat4*)(o + kHalfRow) = b;
 }
 
+// STRICT arithmetic of one bulk row task from its loaded neighbourhood: the reference's expression trees, both
+// tracers packed -- with contraction off every v2 operation is the reference's IEEE operation on each half.  Raw winds.
+__device__ __forceinline__ q8 strict_row(const q8& LT, const q8& CT, const q8& RT, const q8& Tm2, const q8& Tm1, const q8& Tp1,
+                                         const q8& Tp2, const q8& LW, const q8& CW, const q8& RW, const q8& Wm2, const q8& Wm1,
+                                         const q8& Wp1, const q8& Wp2, const f4& xq, const f4& yq, int k, int q,
+                                         const RowK& rk, bool calm_q) {
+#pragma clang fp contract(off)
+  q8 xn;
+  v2 T[12], w[12];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    T[j] = LT.v[j]; T[4 + j] = CT.v[j]; T[8 + j] = RT.v[j];
+    w[j] = LW.v[j]; w[4 + j] = CW.v[j]; w[8 + j] = RW.v[j];
+  }
+  v2 dTx[4], dTy[4], dd[4], da[4];
+  // diffusion (dif_quad<true>)
+  dif_lon_strict(T, w, rk.dif_cc, dTx);
+  if (rk.sub) {
+    v2 T1h[4] = {T[4], T[5], T[6], T[7]};
+    clamp_add(T1h, dTx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - T[4 + i]; // :718
+  }
+  dif_lat_strict(CT, Tm1, Tp1, Wm1, Wp1, rk.dif_ccy, k, NY, dTy);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dd[i] = CW.v[i] * (dTx[i] + dTy[i]); // :721
+  // advection (adv_quad<true>), raw winds
+  if (!rk.sub) {
+    adv_lon_full_strict(T, w, xq.v, rk.adv_cc, dTx);
+  } else {
+    v2 T1h[4] = {T[4], T[5], T[6], T[7]};
+    adv_lon_sub_strict(T, w, xq.v, rk.adv_cc, q == NQ - 1, dTx);
+    clamp_add(T1h, dTx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - T[4 + i]; // :910
+  }
+  adv_lat_strict(CT, Tm2, Tm1, Tp1, Tp2, Wm2, Wm1, Wp1, Wp2, yq.v, rk.adv_ccy, k, NY, dTy);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    da[i] = dTx[i] + dTy[i];                       // :913
+    const v2 xd = T[4 + i] + dd[i];
+    v2 x = xd + da[i];                             // :549
+    if (calm_q) x.y = xd.y;                        // orig :562: vapour diffused, not advected
+    xn.v[i] = x;
+  }
+  return xn;
+}
+
+// the arithmetic of one row in either mode
+template <bool STRICT, bool SUB>
+__device__ __forceinline__ q8 one_row(const q8& LT, const q8& CT, const q8& RT, const q8& Tm2, const q8& Tm1, const q8& Tp1,
+                                      const q8& Tp2, const q8& LW, const q8& CW, const q8& RW, const q8& Wm2, const q8& Wm1,
+                                      const q8& Wp1, const q8& Wp2, const f4& xq, const f4& yq, int k, int q, const RowK& rk,
+                                      bool calm_q) {
+  if (STRICT) return strict_row(LT, CT, RT, Tm2, Tm1, Tp1, Tp2, LW, CW, RW, Wm2, Wm1, Wp1, Wp2, xq, yq, k, q, rk, calm_q);
+  return fast_row<SUB>(LT, CT, RT, Tm2, Tm1, Tp1, Tp2, LW, CW, RW, Wm2, Wm1, Wp1, Wp2, xq, yq, k, q == NQ - 1, rk.dif_cc, rk.dif_ccy,
+                       calm_q);
+}
+
+// the row constants a task needs: everything in STRICT, two words in FAST (the advection constants are folded into
+// the staged winds) -- the full 32-byte read costs the FAST loop 3 %
+template <bool STRICT>
+__device__ __forceinline__ RowK task_consts(const lfloat* lds, int k) {
+  if (STRICT) return row_consts((const lfloat*)(lds + kOffRowK), k);
+  RowK rk{};
+  rk.dif_cc = lds[kOffRowK + k * kRowKWords];
+  rk.dif_ccy = lds[kOffRowK + k * kRowKWords + 2];
+  return rk;
+}
+
+// One bulk row of one quad column.  The five rows k-2 .. k+2 of the column come from ONE base address (the guard
+// rows make k-2 = -1 and k+2 = NY valid reads: zero weights in FAST, not referenced by the reference's boundary
+// formulas in STRICT), the row's left and right quads from the two precomputed offsets.
 template <bool STRICT, bool SUB>
 __device__ __forceinline__ void row_task(lfloat* lds, int cur, const TaskAddr& ta, bool calm_q = false) {
   const int k = ta.kq & 255, q = ta.kq >> 8;
   const lfloat* Xc = lds + kOffX + cur * XB;
   const lfloat* Wc = lds + kOffW;
-  const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
+  const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k); // (the two-word form of task_consts measured 3 % slower HERE)
   const f4 xq = ld4(lds + kOffWX + k * NX + 4 * q), yq = ld4(lds + kOffWY + k * NX + 4 * q);
-  q8 xn;
-  if (STRICT) {
-    const int qm = q == 0 ? NQ - 1 : q - 1, qp = q == NQ - 1 ? 0 : q + 1;
-    const lfloat* xr = Xc + k * RS;
-    const lfloat* wr = Wc + k * RS;
-    // rows beyond the grid do not occur for bulk rows 1..46 except k-2 = -1 / k+2 = 48: clamp the row,
-    // zero the weight
-    const int km2 = k >= 2 ? k - 2 : k, kp2 = k <= NY - 3 ? k + 2 : k;
-    const q8 LT = ld8(xr, qm), CT = ld8(xr, q), RT = ld8(xr, qp);
-    const q8 Tm1 = ld8(xr - RS, q), Tp1 = ld8(xr + RS, q);
-    const q8 Tm2 = ld8(Xc + km2 * RS, q), Tp2 = ld8(Xc + kp2 * RS, q);
-    const q8 LW = ld8(wr, qm), CW = ld8(wr, q), RW = ld8(wr, qp);
-    const q8 Wm1 = ld8(wr - RS, q), Wp1 = ld8(wr + RS, q);
-    const q8 Wm2 = k >= 2 ? ld8(Wc + km2 * RS, q) : zero8();
-    const q8 Wp2 = k <= NY - 3 ? ld8(Wc + kp2 * RS, q) : zero8();
-    // both tracers packed: with contraction off every v2 operation is the reference's IEEE operation on each half
-    {
-#pragma clang fp contract(off)
-      v2 T[12], w[12];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        T[j] = LT.v[j]; T[4 + j] = CT.v[j]; T[8 + j] = RT.v[j];
-        w[j] = LW.v[j]; w[4 + j] = CW.v[j]; w[8 + j] = RW.v[j];
-      }
-      v2 dTx[4], dTy[4], dd[4], da[4];
-      // diffusion (dif_quad<true>)
-      dif_lon_strict(T, w, rk.dif_cc, dTx);
-      if (rk.sub) {
-        v2 T1h[4] = {T[4], T[5], T[6], T[7]};
-        clamp_add(T1h, dTx);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - T[4 + i]; // :718
-      }
-      dif_lat_strict(CT, Tm1, Tp1, Wm1, Wp1, rk.dif_ccy, k, NY, dTy);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dd[i] = CW.v[i] * (dTx[i] + dTy[i]); // :721
-      // advection (adv_quad<true>), raw winds
-      if (!rk.sub) {
-        adv_lon_full_strict(T, w, xq.v, rk.adv_cc, dTx);
-      } else {
-        v2 T1h[4] = {T[4], T[5], T[6], T[7]};
-        adv_lon_sub_strict(T, w, xq.v, rk.adv_cc, q == NQ - 1, dTx);
-        clamp_add(T1h, dTx);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dTx[i] = T1h[i] - T[4 + i]; // :910
-      }
-      adv_lat_strict(CT, Tm2, Tm1, Tp1, Tp2, Wm2, Wm1, Wp1, Wp2, yq.v, rk.adv_ccy, k, NY, dTy);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        da[i] = dTx[i] + dTy[i];                       // :913
-        const v2 xd = T[4 + i] + dd[i];
-        v2 x = xd + da[i];                             // :549
-        if (calm_q) x.y = xd.y;                        // orig :562: vapour diffused, not advected
-        xn.v[i] = x;
-      }
-    }
-  } else {
-    // five rows k-2 .. k+2 of the own column from ONE base (the guard rows make k-2 = -1 and k+2 = NY valid,
-    // zero-weighted reads), the row's left and right quads from the two precomputed offsets
-    const lfloat* xb = Xc + ta.c - 2 * RS;
-    const lfloat* wb = Wc + ta.c - 2 * RS;
-    const q8 Tm2 = ld8p(xb), Tm1 = ld8p(xb + RS), CT = ld8p(xb + 2 * RS), Tp1 = ld8p(xb + 3 * RS), Tp2 = ld8p(xb + 4 * RS);
-    const q8 Wm2 = ld8p(wb), Wm1 = ld8p(wb + RS), CW = ld8p(wb + 2 * RS), Wp1 = ld8p(wb + 3 * RS), Wp2 = ld8p(wb + 4 * RS);
-    const q8 LT = ld8p(Xc + ta.l), RT = ld8p(Xc + ta.r), LW = ld8p(Wc + ta.l), RW = ld8p(Wc + ta.r);
-    xn = fast_row<SUB>(LT, CT, RT, Tm2, Tm1, Tp1, Tp2, LW, CW, RW, Wm2, Wm1, Wp1, Wp2, xq, yq, k, q == NQ - 1, rk.dif_cc,
-                       rk.dif_ccy, calm_q);
-  }
+  const lfloat* xb = Xc + ta.c - 2 * RS;
+  const lfloat* wb = Wc + ta.c - 2 * RS;
+  const q8 Tm2 = ld8p(xb), Tm1 = ld8p(xb + RS), CT = ld8p(xb + 2 * RS), Tp1 = ld8p(xb + 3 * RS), Tp2 = ld8p(xb + 4 * RS);
+  const q8 Wm2 = ld8p(wb), Wm1 = ld8p(wb + RS), CW = ld8p(wb + 2 * RS), Wp1 = ld8p(wb + 3 * RS), Wp2 = ld8p(wb + 4 * RS);
+  const q8 LT = ld8p(Xc + ta.l), RT = ld8p(Xc + ta.r), LW = ld8p(Wc + ta.l), RW = ld8p(Wc + ta.r);
+  const q8 xn = one_row<STRICT, SUB>(LT, CT, RT, Tm2, Tm1, Tp1, Tp2, LW, CW, RW, Wm2, Wm1, Wp1, Wp2, xq, yq, k, q, rk, calm_q);
   st8p(lds + kOffX + (cur ^ 1) * XB + ta.c, xn); // own quad of the other buffer: same offset
 }
 
 // Two vertically adjacent bulk rows (k, k+1) of one quad column in one task: the six rows k-2 .. k+3 of the
 // column are loaded once and shared -- 44 instead of 62 ds_read_b128 for the two rows.  The sub-step loop is
 // co-limited by LDS bandwidth: dropping 39 % of the bulk reads (timing experiment) made it 12 % faster.
-template <bool SUB>
+template <bool STRICT, bool SUB>
 __device__ __forceinline__ void row_task2(lfloat* lds, int cur, const TaskAddr& ta, bool calm_q = false) {
   const int k = ta.kq & 255, q = ta.kq >> 8;
   const lfloat* Xc = lds + kOffX + cur * XB;
@@ -224,37 +236,17 @@ __device__ __forceinline__ void row_task2(lfloat* lds, int cur, const TaskAddr& 
   {
     const q8 LT = ld8p(Xc + ta.l), RT = ld8p(Xc + ta.r), LW = ld8p(Wc + ta.l), RW = ld8p(Wc + ta.r);
     const f4 xq = ld4(lds + kOffWX + k * NX + 4 * q), yq = ld4(lds + kOffWY + k * NX + 4 * q);
-    const float dif_cc = lds[kOffRowK + k * kRowKWords], dif_ccy = lds[kOffRowK + k * kRowKWords + 2];
-    st8p(out, fast_row<SUB>(LT, T2, RT, T0, T1, T3, T4, LW, W2, RW, W0, W1, W3, W4, xq, yq, k, q == NQ - 1, dif_cc, dif_ccy, calm_q));
+    const RowK rk = task_consts<STRICT>(lds, k);
+    st8p(out, one_row<STRICT, SUB>(LT, T2, RT, T0, T1, T3, T4, LW, W2, RW, W0, W1, W3, W4, xq, yq, k, q, rk, calm_q));
   }
   __builtin_amdgcn_sched_barrier(0); // row k+1 after row k: keeps the two rows' temporaries from piling up
   {
     const q8 T5 = ld8p(xb + 5 * RS), W5 = ld8p(wb + 5 * RS); // row k+3: only the second row needs it
     const q8 LT = ld8p(Xc + ta.l + RS), RT = ld8p(Xc + ta.r + RS), LW = ld8p(Wc + ta.l + RS), RW = ld8p(Wc + ta.r + RS);
     const f4 xq = ld4(lds + kOffWX + (k + 1) * NX + 4 * q), yq = ld4(lds + kOffWY + (k + 1) * NX + 4 * q);
-    const float dif_cc = lds[kOffRowK + (k + 1) * kRowKWords], dif_ccy = lds[kOffRowK + (k + 1) * kRowKWords + 2];
-    st8p(out + RS, fast_row<SUB>(LT, T3, RT, T1, T2, T4, T5, LW, W3, RW, W1, W2, W4, W5, xq, yq, k + 1, q == NQ - 1, dif_cc, dif_ccy,
-                                 calm_q));
+    const RowK rk = task_consts<STRICT>(lds, k + 1);
+    st8p(out + RS, one_row<STRICT, SUB>(LT, T3, RT, T1, T2, T4, T5, LW, W3, RW, W1, W2, W4, W5, xq, yq, k + 1, q, rk, calm_q));
   }
-}
-
-// task index -> row
-__device__ __forceinline__ int sub_row(int r) { return r < 9 ? 1 + r : 38 + (r - 9); } // r = 0..17
-constexpr int kSubTasks = 18 * NQ, kFullTasks = 28 * NQ;
-
-// waves 0-5: three passes each.  Pass ids 0-6 = sub passes, 7-17 = full passes (a sub pass costs ~1.5 full
-// passes: 340 vs 228 instructions).  Waves w and w+4 share a SIMD, and SIMDs 2 and 3 also carry the polar
-// waves 6 and 7 (~900 instructions per sub-step each), so waves 2 and 3 get the light end of the deal:
-//   wave:  0        1        2         3           4          5
-//          0,1,7    2,3,8    4,9,10    11,12,13    5,14,15    6,16,17
-//   SIMD:  0: 3 sub + 3 full   1: 3 sub + 3 full   2: 1 sub + 2 full + pole   3: 3 full + pole
-// The ids are arithmetic in the wave number so they live in SGPRs: a __constant__ table costs a scalar-cache
-// load per pass inside the sub-step loop.
-__device__ __forceinline__ int pass_of(int wave, int i) {
-  if (wave < 2) return i < 2 ? 2 * wave + i : 7 + wave;
-  if (wave == 2) return i == 0 ? 4 : 8 + i;
-  if (wave == 3) return 11 + i;
-  return i == 0 ? wave + 1 : 14 + 2 * (wave - 4) + (i - 1);
 }
 
 struct BulkTasks { TaskAddr t[3]; };
@@ -269,7 +261,7 @@ struct BulkTasks { TaskAddr t[3]; };
 // polar wave) -> waves 6, 7; slots 4, 5 -> waves 4, 5.
 __device__ __forceinline__ int bulk_slot(int wave) { return wave >= 6 ? wave - 4 : wave; }
 
-// FAST schedule.  Task kinds: one row (S1 sub-cycled family, F1 full family) or two stacked rows (ST, FT).
+// The schedule (both arithmetic modes).  Task kinds: one row (S1 sub-cycled family, F1 full family) or two stacked rows (ST, FT).
 //   ST  rows (1,2) (3,4) (5,6) (7,8) (39,40) .. (45,46) : 8 pairs x 24 quads = 3 full passes
 //   FT  rows (10,11) .. (24,25)                          : 8 pairs x 24 quads = 3 full passes
 //   S1  rows 9, 38                                       : 48 tasks, one pass
@@ -310,17 +302,8 @@ __device__ __forceinline__ BulkTasks make_tasks(int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     int k = 1, q = 0, valid = 0;
-    if (STRICT) { // one row per task, 18 passes (pass_of)
-      const int pass = pass_of(wave, i);
-      if (pass < 7) {
-        const int t = pass * 64 + lane;
-        valid = t < kSubTasks; k = sub_row((valid ? t : 0) / NQ); q = (valid ? t : 0) % NQ;
-      } else {
-        const int t = (pass - 7) * 64 + lane;
-        valid = t < kFullTasks; k = 10 + (valid ? t : 0) / NQ; q = (valid ? t : 0) % NQ;
-      }
-    } else {
-      const int w6 = wave, kind = fast_kind(w6, i), t = fast_index(w6, i) * 64 + lane;
+    {
+      const int kind = fast_kind(wave, i), t = fast_index(wave, i) * 64 + lane;
       const int r = t / NQ;
       q = t % NQ;
       if (kind == kST) { valid = r < 8; k = r < 4 ? 1 + 2 * r : 39 + 2 * (r - 4); }
@@ -344,22 +327,12 @@ template <bool STRICT>
 __device__ __forceinline__ void bulk_substep(lfloat* lds, int cur, int wave, const BulkTasks& tasks, int dbg, bool calm_q = false) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    if (STRICT) {
-      const int pass = __builtin_amdgcn_readfirstlane(pass_of(wave, i));
-      if (tasks.t[i].kq < 0) continue;
-      if (pass < 7) {
-        if (!(dbg & 1)) row_task<STRICT, true>(lds, cur, tasks.t[i], calm_q);
-      } else {
-        if (!(dbg & 2)) row_task<STRICT, false>(lds, cur, tasks.t[i], calm_q);
-      }
-    } else {
-      const int kind = __builtin_amdgcn_readfirstlane(fast_kind(wave, i));
-      if (kind == kNone || tasks.t[i].kq < 0) continue;
-      if (kind == kS1) { if (!(dbg & 1)) row_task<false, true>(lds, cur, tasks.t[i], calm_q); }
-      else if (kind == kF1) { if (!(dbg & 2)) row_task<false, false>(lds, cur, tasks.t[i], calm_q); }
-      else if (kind == kST) { if (!(dbg & 1)) row_task2<true>(lds, cur, tasks.t[i], calm_q); }
-      else { if (!(dbg & 2)) row_task2<false>(lds, cur, tasks.t[i], calm_q); }
-    }
+    const int kind = __builtin_amdgcn_readfirstlane(fast_kind(wave, i));
+    if (kind == kNone || tasks.t[i].kq < 0) continue;
+    if (kind == kS1) { if (!(dbg & 1)) row_task<STRICT, true>(lds, cur, tasks.t[i], calm_q); }
+    else if (kind == kF1) { if (!(dbg & 2)) row_task<STRICT, false>(lds, cur, tasks.t[i], calm_q); }
+    else if (kind == kST) { if (!(dbg & 1)) row_task2<STRICT, true>(lds, cur, tasks.t[i], calm_q); }
+    else { if (!(dbg & 2)) row_task2<STRICT, false>(lds, cur, tasks.t[i], calm_q); }
   }
 }
 
