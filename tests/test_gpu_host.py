@@ -113,3 +113,24 @@ def test_plain_c_driver(tmp_path, inputs):
     assert rows.shape == (3, 4) and np.abs(rows[:, 2:] - g["yearly"]).max() < 2e-3
     r = subprocess.run([exe, str(tmp_path / "nonexistent"), str(out), "1", "1", "680"], capture_output=True, text=True)
     assert r.returncode == 2 and "cannot open" in r.stderr
+
+
+def test_host_pads_a_short_co2_series(tmp_path, inputs):
+    """The Fortran host applies the reference's padding rule (src/greb.f90:1053-1061): `co2_ppm = 400, 520` with
+    time_scnr = 3 runs the third year at 520 ppm, like the reference run the golden file comes from."""
+    from greb_climate_model_amd import build, workload
+    host = os.path.join(build.PKG, "greb_host")
+    if not os.path.exists(host):
+        pytest.skip("greb_host not built (no Fortran compiler at build time)")
+    g = load_golden("co2series_g96.npz")
+    inputs.write_input_dir(str(tmp_path / "input"))
+    os.makedirs(tmp_path / "output")
+    workload.write_namelist(str(tmp_path / "namelist"), 1, 3, (400.0, 520.0), 95, 38)
+    r = subprocess.run([host], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    mon = workload.read_greb(str(tmp_path / "output" / "scenario"))
+    for j, month in enumerate((11, 23, 35)):
+        for i, tol in enumerate((1e-4, 1e-4, 1e-4, 2e-8, 1e-6)):
+            assert rms(mon[month, i], g["decembers"][j, i]) < tol, (month, i)
+    rows = [[float(x) for x in l.split()] for l in r.stdout.splitlines() if len(l.split()) == 4 and l.split()[0][0].isdigit()]
+    assert [r_[1] for r_ in rows[1:]] == [400.0, 520.0, 520.0]

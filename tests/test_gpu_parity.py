@@ -288,3 +288,26 @@ def test_bad_arguments_are_errors_with_messages(eng_mod, params, inputs):
     e.close()
     with pytest.raises(eng_mod.GrebError):  # batched routines: same validation
         eng_mod.diffusion(np.zeros((48, 94), np.float32), np.ones((48, 94), np.float32), params)
+
+
+def test_co2_series_vs_reference(eng_mod, params, inputs):
+    """A CO2 concentration that changes from year to year (src/greb.f90:918-926 picks co2_ppm by model year): 1+3 yr
+    with 400, 520, 520 ppm against the reference Fortran run with the namelist series `400, 520` (which it pads)."""
+    g = load_golden("co2series_g96.npz")
+    e = eng_mod.Engine(inputs, params)
+    yf = e.flux_correction(1)
+    mon, yr = e.run(3, g["co2"])
+    e.close()
+    mon = mon[0].reshape(36, 5, 48, 96)
+    for j, month in enumerate((11, 23, 35)):
+        for i, tol in enumerate((1e-4, 1e-4, 1e-4, 2e-8, 1e-6)):
+            assert rms(mon[month, i], g["decembers"][j, i]) < tol, (month, i)
+    assert np.abs(mon.astype(np.float64).mean((2, 3)) - g["stats"][:, :, 0]).max() < 1e-4
+    assert np.abs(np.concatenate([yf[0], yr[0]]) - g["yearly"]).max() < 2e-3
+    # two calls of one and two years continue the same series (the model year advances across calls)
+    e = eng_mod.Engine(inputs, params)
+    e.flux_correction(1)
+    a, _ = e.run(1, g["co2"][:1])
+    b, _ = e.run(2, g["co2"][1:])
+    e.close()
+    assert np.array_equal(np.concatenate([a[0], b[0]]).reshape(36, 5, 48, 96), mon)

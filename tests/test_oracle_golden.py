@@ -101,3 +101,17 @@ def test_run_default_statistics(inputs, params, oracle_lib):
     assert np.allclose(mon.astype(np.float64).mean((2, 3)), g["stats"][:12, :, 0], rtol=0, atol=1e-9)
     assert np.array_equal(yr[0], g["yearly"][3])
     o.close()
+
+
+def test_co2_series_run_bit_exact(inputs, params, oracle_lib):
+    """Time-varying CO2 (src/greb.f90:918-926): 1+3 yr with the series 400, 520, 520 -- the reference's own padding of a
+    two-value namelist series (:1053-1061) -- reproduced bit for bit."""
+    import hashlib
+    g = load_golden("co2series_g96.npz")
+    o = oracle_lib.Oracle(inputs, params)
+    o.flux_correction(1)
+    mon, _ = o.run(3, g["co2"])
+    o.close()
+    mon = mon.reshape(36, 5, 48, 96)
+    assert hashlib.sha256(np.ascontiguousarray(mon).tobytes()).digest() == g["sha256"].tobytes()
+    assert np.array_equal(mon[[11, 23, 35]], g["decembers"])
