@@ -326,3 +326,20 @@ def test_nondefault_physics_par_vs_reference(eng_mod, inputs, strict):
     e.close()
     _check_run(mon[0].reshape(12, 5, 48, 96), g["monthly"], f"physics_par strict={strict}")
     assert np.abs(np.concatenate([yf[0], yr[0]]) - g["yearly"]).max() < 2e-3
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_run_without_flux_correction_vs_reference(eng_mod, params, inputs, strict):
+    """time_flux = 0: the engine's corrections stay zero and the scenario starts from the initial state, like the
+    reference run with that namelist (the model drifts several K in a year -- a sensitive comparison)."""
+    g = load_golden("noflux_g96.npz")
+    e = eng_mod.Engine(inputs, params, strict=strict)
+    assert e.flux_correction(0).shape[1] == 0
+    mon, yr = e.run(1, 680.0)
+    e.close()
+    mon = mon[0].reshape(12, 5, 48, 96)
+    for j, month in enumerate((0, 5, 11)):
+        for i, tol in enumerate((1e-4, 1e-4, 1e-4, 2e-8, 1e-6)):
+            assert rms(mon[month, i], g["months"][j, i]) < tol, (month, i)
+    assert np.abs(mon.astype(np.float64).mean((2, 3)) - g["stats"][:, :, 0]).max() < 1e-4
+    assert np.abs(yr[0] - g["yearly"]).max() < 2e-3

@@ -129,3 +129,14 @@ def test_nondefault_physics_par_bit_exact(inputs, oracle_lib):
     mon, _ = o.run(1, 680.0)
     o.close()
     assert np.array_equal(mon.reshape(12, 5, 48, 96), g["monthly"])
+
+
+def test_run_without_flux_correction_bit_exact(inputs, params, oracle_lib):
+    """time_flux = 0: zero corrections, scenario from the initial state; 0+1 yr bit for bit."""
+    import hashlib
+    g = load_golden("noflux_g96.npz")
+    o = oracle_lib.Oracle(inputs, params)
+    mon, _ = o.run(1, 680.0)
+    o.close()
+    mon = mon.reshape(12, 5, 48, 96)
+    assert hashlib.sha256(np.ascontiguousarray(mon).tobytes()).digest() == g["sha256"].tobytes()
