@@ -343,3 +343,32 @@ def test_run_without_flux_correction_vs_reference(eng_mod, params, inputs, stric
             assert rms(mon[month, i], g["months"][j, i]) < tol, (month, i)
     assert np.abs(mon.astype(np.float64).mean((2, 3)) - g["stats"][:, :, 0]).max() < 1e-4
     assert np.abs(yr[0] - g["yearly"]).max() < 2e-3
+
+
+def test_engine_g192_vs_oracle(eng_mod, oracle_lib):
+    """A grid that is neither of the two BASELINE ones (runtime grid sizes): 192x96, bilinear-upsampled
+    inputs, every row sub-cycled, 10 rows iterating (up to 129 sweeps).  Batched STRICT stencils bit-exact and a 1+1-yr
+    run in both arithmetic modes against the oracle at that grid (any-grid multi-launch engine)."""
+    from greb_climate_model_amd import abi, workload
+    inp = workload.make_inputs(192, 96)
+    p = abi.default_params(ipx=190, ipy=75)
+    o = oracle_lib.Oracle(inp, p)
+    g = o.grid()
+    assert int(g["dif_time2"].max()) == 129 and int((g["dif_time2"] > 1).sum()) == 10
+    T, q = inp.tclim[100], inp.qclim[100]
+    wa, wv = o.field(5).copy(), o.field(6).copy()
+    u, v = inp.uclim[100], inp.vclim[100]
+    assert np.array_equal(eng_mod.diffusion(np.stack([T, q]), np.stack([wa, wv]), p, strict=True),
+                          np.stack([o.diffusion(T, wa), o.diffusion(q, wv)]))
+    assert np.array_equal(eng_mod.advection(np.stack([T, q]), np.stack([wa, wv]), np.stack([u, u]), np.stack([v, v]), p, strict=True),
+                          np.stack([o.advection(T, wa, u=u, v=v), o.advection(q, wv, u=u, v=v)]))
+    yfo = o.flux_correction(1)
+    ref, yro = o.run(1, 680.0)
+    o.close()
+    for strict in (True, False):
+        e = eng_mod.Engine(inp, p, strict=strict)
+        yf = e.flux_correction(1)
+        mon, yr = e.run(1, 680.0)
+        e.close()
+        _check_run(mon[0, 0], ref[0], f"g192 strict={strict}")
+        assert np.abs(yf[0] - yfo).max() < 2e-3 and np.abs(yr[0] - yro).max() < 2e-3
