@@ -160,6 +160,14 @@ def main():
             "device": engine.device_info(local_rank),
         }
         out.update(extra)
+        # the engine itself is not HBM-bound: its algorithmic arithmetic, 77 flop per point, tracer and
+        # circulation sub-step = 12.4 GFLOP per member-year at 96x48, against the fp32 vector peak (an FMA counts 2)
+        gflop_my = 2 * 77.0 * 96 * 48 * 24 * 730 / 1e9
+        out["engine_arithmetic"] = {"algorithmic_gflop_per_member_year": round(gflop_my, 2),
+                                    "achieved_tflops_per_gpu": round(value / world * gflop_my / 1e3, 2),
+                                    "peak_fp32_vector_tflops": 157.3,
+                                    "frac": round(value / world * gflop_my / 1e3 / 157.3, 4),
+                                    "bound": "VALU issue + LDS bandwidth (DESIGN.md section 4)"}
         if roof is not None:
             out["roofline"] = roof
         if cpu is not None:
