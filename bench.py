@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -39,17 +39,97 @@ def main():
     ap.add_argument("--strict", action="store_true", help="reference operation order (bit-exact stencils)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-g384", action="store_true", help="skip the 384x192 object (BASELINE configs 3 and 5)")
     ap.add_argument("--roofline-batch", type=int, default=16384)
-    args = ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="bring the ranks up (gloo, no GPU call), print the member partition, exit")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` run directly: this parent starts N rank processes (one per GPU), relays rank 0's
+    JSON line and fails if any rank fails.  It never touches the GPU (no torch import at all), and it starts the
+    ranks as CHILD processes -- a process that has initialised the GPU must never be re-exec'ed.  The reference's
+    own ensemble convention is the same: N processes with N ens_ids (src/greb.f90:153,1064-1068)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    rc, out0 = 0, ""
+    try:
+        pending = set(range(args.gpus))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    out0 = procs[0].stdout.read()
+                if code != 0 and rc == 0:  # one rank failed: the others would wait in a collective for ever
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            if pending:
+                try:
+                    procs[min(pending)].wait(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    pass
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if rc == 0 and not any(line.startswith("{") for line in out0.splitlines()):
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def dry_launch(world, rank, members):
+    """--dry-launch: rendezvous over gloo and report how the ensemble is dealt to the ranks; no GPU call."""
+    import torch.distributed as dist
+    from greb_climate_model_amd import ensemble
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = ensemble.partition(world * members, world, rank)
+    mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "first": int(ids[0]), "count": int(len(ids)),
+            "co2_first": float(ensemble.co2_sweep(world * members)[ids[0]])}
+    parts = [mine]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "members_per_gpu": members, "partition": parts}))
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: refusing to measure a different GPU count "
+              f"than the one asked for", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_launch:
+        return dry_launch(world, rank, args.members)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     # rehearsal knobs for a one-GPU box (N ranks sharing the card over gloo); never set by the driver
     backend = os.environ.get("GREB_BENCH_BACKEND", "nccl")
     if "GREB_BENCH_DEVICE" in os.environ:

@@ -17,6 +17,32 @@ def co2_sweep(n_members: int, lo: float = 280.0, hi: float = 1120.0) -> np.ndarr
     return (lo + (hi - lo) * np.arange(n_members, dtype=np.float64) / (n_members - 1)).astype(np.float32)
 
 
+def splitmix64(seed: int, n: int) -> np.ndarray:
+    """n deterministic uniforms in [0,1) from SplitMix64."""
+    out, x, M = [], seed & (2**64 - 1), 2**64 - 1
+    for _ in range(n):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        out.append((z >> 11) / float(1 << 53))
+    return np.asarray(out)
+
+
+PERTURBED = ("da_ice", "a_no_ice", "a_cloud", "kappa")
+
+
+def perturbed_physics(n_members: int, params, seed: int = 20261004, spread: float = 0.1) -> np.ndarray:
+    """BASELINE config 5's members: albedo (da_ice, a_no_ice, a_cloud) and diffusivity (kappa) drawn uniformly within
+    +-`spread` of the namelist value, member index as the stream position.  Returns float32
+    [n_members][4] in the order of greb_member_overrides -- what N separate `ens_id` processes with N different
+    &PHYSICS_PAR groups are in the reference (src/greb.f90:128-132,153)."""
+    u = splitmix64(seed, 4 * n_members).reshape(n_members, 4)
+    base = np.asarray([getattr(params, k) for k in PERTURBED], np.float64)
+    return (base[None] * (1.0 - spread + 2.0 * spread * u)).astype(np.float32)
+
+
 def partition(n_members: int, world: int, rank: int) -> np.ndarray:
     """Global member ids owned by `rank`: contiguous blocks, sizes differing by at most one."""
     base, rem = divmod(n_members, world)

@@ -1,0 +1,50 @@
+"""CPU: `python bench.py --gpus N` launches its own ranks.  The parent never touches the GPU;
+the ranks rendezvous on 127.0.0.1 and each owns a contiguous block of the ensemble (members are what
+separate `ens_id` processes are in the reference, src/greb.f90:153,1064-1068)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def _json_line(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, text
+    return json.loads(lines[0])
+
+
+def test_dry_launch_two_ranks_partition():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--members", "6", "--dry-launch"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["dry_launch"] is True
+    parts = out["partition"]
+    assert [p["rank"] for p in parts] == [0, 1] and [p["local_rank"] for p in parts] == [0, 1]
+    assert [(p["first"], p["count"]) for p in parts] == [(0, 6), (6, 6)]  # weak scaling: M members per GPU
+    assert parts[0]["co2_first"] == 280.0 and 280.0 < parts[1]["co2_first"] < 1120.0
+
+
+def test_gpus_flag_must_match_world_size():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-launch"], env=_env(WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_failing_rank_fails_the_launch():
+    # no visible GPU: every rank fails at its first GPU call; the parent must report failure, not a JSON line
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--members", "1"],
+                       env=_env(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

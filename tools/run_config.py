@@ -22,19 +22,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def splitmix64(seed, n):
-    """Deterministic uniforms in [0,1): SplitMix64."""
-    out, x, M = [], seed & (2**64 - 1), 2**64 - 1
-    for _ in range(n):
-        x = (x + 0x9E3779B97F4A7C15) & M
-        z = x
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
-        z ^= z >> 31
-        out.append((z >> 11) / float(1 << 53))
-    return np.asarray(out)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("config", type=int, choices=[2, 3, 4, 5])
@@ -67,9 +54,8 @@ def main():
     if cfg == 4:
         co2 = np.repeat(ensemble.co2_sweep(8)[ids][:, None], years, 1)
     if cfg == 5:
-        u = splitmix64(20261004, 4 * n_total).reshape(n_total, 4)
-        base = dict(da_ice=p.da_ice, a_no_ice=p.a_no_ice, a_cloud=p.a_cloud, kappa=p.kappa)
-        overrides = [{k: float(np.float32(base[k] * (0.9 + 0.2 * u[g, j]))) for j, k in enumerate(base)} for g in ids]
+        ov = ensemble.perturbed_physics(n_total, p)
+        overrides = [{k: float(ov[g, j]) for j, k in enumerate(ensemble.PERTURBED)} for g in ids]
     out = {"config": cfg, "grid": [inp.nx, inp.ny], "members_total": n_total, "members_this_rank": len(ids),
            "time_flux": tf, "time_scnr": years, "n_gpus": world, "arithmetic": "strict" if args.strict else "fast"}
     t0 = time.perf_counter()
