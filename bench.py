@@ -221,9 +221,12 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         roof = roofline_diffusion(torch, engine, params, args.roofline_batch, args.strict)
-    cpu = None
+    cpu = cpu_all = delivered = None
+    if rank == 0 and world == 1:
+        delivered = host_delivered(torch, eng, levels, M, min(K, 4))
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(inp)
+        cpu_all = cpu_baseline_all_cores(inp)
 
     if rank == 0:
         out = {
@@ -250,8 +253,12 @@ def main():
                                     "bound": "VALU issue + LDS bandwidth (DESIGN.md section 4)"}
         if roof is not None:
             out["roofline"] = roof
+        if delivered is not None:
+            out["host_delivered"] = delivered
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if cpu_all is not None:
+            out["cpu_baseline_all_cores"] = cpu_all
         print(json.dumps(out))
     eng.close()
     if world > 1:
@@ -305,6 +312,83 @@ def roofline_diffusion(torch, engine, params, batch, strict, sweeps=20):
             "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(avg * 1e3, 4), "batch": batch,
             "min_launch_ms": round(float(np.min(ms)), 4), "measured_copy_GBps": round(copy_gbs, 1),
             "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
+
+
+def host_delivered(torch, eng, levels, M, years):
+    """The same ensemble years with the monthly means DELIVERED TO HOST MEMORY inside the timed region -- where the
+    reference's path ends (its output() writes them to disk, src/greb.f90:962-987).  `value` keeps them in HBM; this
+    is the PCIe-inclusive rate: year y's 1.1 MB per member leave on a copy stream while year y+1 integrates."""
+    np_ = eng.np
+    buf = torch.empty((M, years, 12, 5, np_), dtype=torch.float32, pin_memory=True)
+    co2 = np.repeat(levels[:, None], years, 1)
+    eng.run(1, levels[:, None], out=buf.numpy().reshape(-1)[: M * 12 * 5 * np_])  # warm the copy path
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(years, co2, out=buf.numpy().reshape(-1))
+    dt = time.perf_counter() - t0
+    return {"value": round(M * years / dt, 2), "unit": "simulated-years/s", "years": years,
+            "bytes_to_host_per_year": int(M * 12 * 5 * np_ * 4), "host_memory": "pinned",
+            "finite": bool(torch.isfinite(buf).all().item())}
+
+
+def usable_cores():
+    """Host cores this process may use: the affinity mask, capped by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline_all_cores(inp, years=(1, 3), cap=64):
+    """The reference's own ensemble convention on the host: N independent single-threaded processes, one per core
+    (src/greb.f90:153,1064-1068 -- N namelists with N ens_ids; its only threading hook, the omp sections at
+    :299-304, is not enabled by its Makefile).  N = min(usable cores, 64); bounded sample = 1+3 model-years each;
+    aggregate rate = N x 4 / wall of the slowest."""
+    import shutil
+    import subprocess
+    import tempfile
+    from greb_climate_model_amd import workload
+    from oracle import oracle as O  # checker/baseline only -- never on the product path
+    if not os.path.exists(O.REF_BIN):
+        return None
+    n = max(1, min(usable_cores(), cap))
+    tf, ts = years
+    root = tempfile.mkdtemp(prefix="greb_cpu_all_")
+    try:
+        inp.write_input_dir(os.path.join(root, "input"))
+        procs = []
+        for i in range(n):
+            wd = os.path.join(root, f"m{i:03d}")
+            os.makedirs(os.path.join(wd, "output"))
+            os.symlink(os.path.join(root, "input"), os.path.join(wd, "input"))
+            workload.write_namelist(os.path.join(wd, "namelist"), tf, ts, (280.0 + 840.0 * i / max(n - 1, 1),), 95, 38,
+                                    ens_id=f"{i:03d}")
+        t0 = time.perf_counter()
+        for i in range(n):
+            procs.append(subprocess.Popen([O.REF_BIN], cwd=os.path.join(root, f"m{i:03d}"), stdout=subprocess.DEVNULL,
+                                          stderr=subprocess.DEVNULL))
+        rcs = [p.wait() for p in procs]
+        wall = time.perf_counter() - t0
+        ok = all(rc == 0 for rc in rcs) and all(
+            os.path.getsize(os.path.join(root, f"m{i:03d}", "output", f"scenario_{i:03d}")) == ts * 60 * 96 * 48 * 4 for i in range(n))
+        if not ok:
+            return {"error": "a reference process failed", "cores": n}
+        return {"value": round(n * (tf + ts) / wall, 2), "unit": "simulated-years/s", "cores": n, "kind": "reference",
+                "sample": f"{n} independent reference processes (amdflang -O2), one per core, {tf}+{ts} model-years each, "
+                          f"96x48, CO2 sweep, same synthetic inputs", "wall_s": round(wall, 2)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def cpu_baseline(inp):

@@ -13,6 +13,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libgreb_hip.so")
+# the same sources with -DGREB_TUNING: the timing-experiment knobs of tools/ (GREB_DEBUG_SKIP, GREB_DEBUG_NSUB, ...)
+# exist only in this variant; the release library above never reads the environment
+LIB_TUNING = os.path.join(PKG, "libgreb_hip_tuning.so")
 SOURCES = ["greb_engine.cpp", "greb_kernels.hip", "greb_member.hip", "greb_ensemble.hip", "greb_pair_sweep.hip"]
 HEADERS = ["greb_device.h", "greb_kernels.h", "greb_stencil.h", "greb_pair.h", "greb_physics_step.h", os.path.join(ROOT, "include", "greb_engine.h")]
 # -O2: measured 1.4 % faster than -O3 on the fused member kernel (3 790 vs 3 735 yr/s), equal elsewhere
@@ -24,22 +27,24 @@ def hipcc() -> str:
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc(), *HIPCC_FLAGS, "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
+def build_lib(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+    lib = LIB_TUNING if tuning else LIB
+    if not force and not needs_build(lib):
+        return lib
+    cmd = [hipcc(), *HIPCC_FLAGS, *(["-DGREB_TUNING"] if tuning else []), "-o", lib,
+           *[os.path.join(CSRC, s) for s in SOURCES]]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    return lib
 
 
 def build_host(verbose: bool = False) -> str | None:

@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -109,6 +111,9 @@ struct greb_engine {
   float* W2p = nullptr; // [np][{wz_air,wz_vapor}] for the pair form of the sub-step (FAST, 384-wide grids)
   bool pairs = false;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;               // device -> host delivery of the monthly means
+  hipEvent_t ev_done[2] = {nullptr, nullptr};      // year written into staging slot i
+  hipEvent_t ev_free[2] = {nullptr, nullptr};      // staging slot i copied out
   // device
   float *z_topo = nullptr, *glacier = nullptr, *sw_solar = nullptr;
   float *tclim = nullptr, *qclim = nullptr, *uclim = nullptr, *vclim = nullptr, *mldclim = nullptr,
@@ -152,7 +157,7 @@ MemberArgs base_args(greb_engine* e) {
   a.state = e->state; a.acc = e->acc; a.corr = e->corr; a.corr_index = e->corr_index;
   a.tabs = e->tabs; a.tab_index = e->tab_index; a.phys = e->phys;
   a.nsub = nsub_of(e->p);
-  if (const char* ns = getenv("GREB_DEBUG_NSUB")) a.nsub = atoi(ns); // timing experiments only
+  a.nsub = tuning_int("GREB_DEBUG_NSUB", a.nsub); // -DGREB_TUNING builds only
   a.co2_flux = e->p.co2_flux;
   a.ipx = e->p.ipx; a.ipy = e->p.ipy;
   a.xsw = e->xsw;
@@ -388,6 +393,11 @@ int greb_engine_destroy(greb_engine* e) {
                   e->corr, e->corr_index, e->tab_index, e->tabs, e->phys, e->co2_dev, e->monthly_dev, e->yearly_dev,
                   e->Xa, e->Xb, e->red, e->W2, e->W2p};
   for (void* q : ptrs) if (q) (void)hipFree(q);
+  for (int i = 0; i < 2; ++i) {
+    if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
+    if (e->ev_free[i]) (void)hipEventDestroy(e->ev_free[i]);
+  }
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return 0;
@@ -435,30 +445,54 @@ int greb_engine_run(greb_engine* e, int years, const float* co2_ppm, float* mont
   HIP_TRY(e, hipMemcpyAsync(e->co2_dev, co2_ppm, nm * years * sizeof(float), hipMemcpyHostToDevice, e->stream));
   if (int rc = ensure(e, &e->yearly_dev, &e->yearly_cap, nm * years * 2)) return rc;
   HIP_TRY(e, hipMemsetAsync(e->yearly_dev, 0, nm * years * 2 * sizeof(float), e->stream));
-  int chunk = years;
-  if (!dev_out) {
-    const size_t budget = (size_t)1 << 30; // floats (4 GiB) of staging per chunk
-    chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)years, budget / (nm * rec_year)));
-    if (int rc = ensure(e, &e->monthly_dev, &e->monthly_cap, nm * chunk * rec_year)) return rc;
-  }
-  for (int y0 = 0; y0 < years; y0 += chunk) {
-    const int cy = std::min(chunk, years - y0);
-    for (int y = 0; y < cy; ++y) {
+  if (dev_out) {
+    for (int y = 0; y < years; ++y) {
       MemberArgs a = base_args(e);
       a.flux_phase = 0;
-      a.it0 = e->it_scnr + 1 + (long long)(y0 + y) * kNT; a.nsteps = kNT;
-      a.co2 = e->co2_dev; a.co2_stride = years; a.co2_year0 = y0 + y;
-      if (dev_out) { a.monthly = monthly; a.monthly_years = years; a.year_out0 = y0 + y; }
-      else { a.monthly = e->monthly_dev; a.monthly_years = chunk; a.year_out0 = y; }
-      a.yearly = e->yearly_dev; a.yearly_years = years; a.yearly_year0 = y0 + y;
+      a.it0 = e->it_scnr + 1 + (long long)y * kNT; a.nsteps = kNT;
+      a.co2 = e->co2_dev; a.co2_stride = years; a.co2_year0 = y;
+      a.monthly = monthly; a.monthly_years = years; a.year_out0 = y;
+      a.yearly = e->yearly_dev; a.yearly_years = years; a.yearly_year0 = y;
       if (int rc = run_year(e, a, e->nm)) return rc;
     }
-    if (!dev_out) {
-      HIP_TRY(e, hipMemcpy2DAsync(monthly + (size_t)y0 * rec_year, (size_t)years * rec_year * sizeof(float),
-                                  e->monthly_dev, (size_t)chunk * rec_year * sizeof(float),
-                                  (size_t)cy * rec_year * sizeof(float), nm, hipMemcpyDeviceToHost, e->stream));
-      HIP_TRY(e, hipStreamSynchronize(e->stream));
+  } else {
+    // Host delivery: year y's records leave over PCIe on the copy stream while year y+1 integrates on the compute
+    // stream (two staging slots of one model year each, [member][12][5][np]); the host side is strided by the
+    // caller's [member][years] layout.  A pinned `monthly` makes the copies true DMA; a pageable one is staged by
+    // the runtime and still overlaps the kernels.
+    const size_t slot = nm * rec_year;
+    if (int rc = ensure(e, &e->monthly_dev, &e->monthly_cap, 2 * slot)) return rc;
+    if (!e->copy_stream) HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      if (!e->ev_done[i]) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming));
+      if (!e->ev_free[i]) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_free[i], hipEventDisableTiming));
     }
+    // copy of year y: issued AFTER year y+1's kernels are enqueued, so that even a copy the runtime performs
+    // synchronously (pageable destination) runs beside a kernel
+    auto deliver = [&](int y) -> int {
+      const int sl = y & 1;
+      HIP_TRY(e, hipStreamWaitEvent(e->copy_stream, e->ev_done[sl], 0));
+      HIP_TRY(e, hipMemcpy2DAsync(monthly + (size_t)y * rec_year, (size_t)years * rec_year * sizeof(float),
+                                  e->monthly_dev + (size_t)sl * slot, rec_year * sizeof(float), rec_year * sizeof(float),
+                                  nm, hipMemcpyDeviceToHost, e->copy_stream));
+      HIP_TRY(e, hipEventRecord(e->ev_free[sl], e->copy_stream));
+      return 0;
+    };
+    for (int y = 0; y < years; ++y) {
+      const int sl = y & 1;
+      if (y >= 2) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_free[sl], 0)); // slot's previous year has left
+      MemberArgs a = base_args(e);
+      a.flux_phase = 0;
+      a.it0 = e->it_scnr + 1 + (long long)y * kNT; a.nsteps = kNT;
+      a.co2 = e->co2_dev; a.co2_stride = years; a.co2_year0 = y;
+      a.monthly = e->monthly_dev + (size_t)sl * slot; a.monthly_years = 1; a.year_out0 = 0;
+      a.yearly = e->yearly_dev; a.yearly_years = years; a.yearly_year0 = y;
+      if (int rc = run_year(e, a, e->nm)) return rc;
+      HIP_TRY(e, hipEventRecord(e->ev_done[sl], e->stream));
+      if (y > 0) if (int rc = deliver(y - 1)) return rc;
+    }
+    if (int rc = deliver(years - 1)) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->copy_stream));
   }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->it_scnr += (long long)years * kNT;
@@ -544,18 +578,50 @@ int batched_common(const greb_params* p, int nx, int ny, int batch, int device) 
 
 #define HIP_TRY0(expr) HIP_TRY(nullptr, expr)
 
+namespace {
+struct TabCache {
+  struct Entry { RowTables* dev = nullptr; RowTables host; bool valid = false; };
+  std::mutex mu;
+  std::map<int, Entry> by_device;
+} g_tab_cache;
+} // namespace
+
+int greb_release_caches(void) {
+  std::lock_guard<std::mutex> lock(g_tab_cache.mu);
+  int prev = 0;
+  const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+  for (auto& kv : g_tab_cache.by_device)
+    if (kv.second.dev && hipSetDevice(kv.first) == hipSuccess) (void)hipFree(kv.second.dev);
+  g_tab_cache.by_device.clear();
+  if (have_prev) (void)hipSetDevice(prev);
+  return 0;
+}
+
 int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, const float* T1_dev,
                                const float* wz_dev, float* dX_dev, int strict, int sweeps, void* stream) {
   if (!p || nx < 12 || (nx & 3) || ny < 5 || ny > kMaxNy || batch < 1 || sweeps < 1)
     return fail(nullptr, GREB_E_INVALID, "diffusion_batched_dev: bad argument");
-  // table lives in a small cached device buffer keyed by (params, grid)
-  static thread_local RowTables* tab_dev = nullptr;
-  static thread_local RowTables tab_host;
+  // The row table lives in a small device buffer cached PER DEVICE (the launches must not be separated by an
+  // allocation or a copy: this entry point is what the HBM-roofline measurement times).  The operands must live on
+  // the calling thread's current device.
+  int dev = 0;
+  HIP_TRY0(hipGetDevice(&dev));
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, T1_dev) != hipSuccess || attr.device != dev) {
+    (void)hipGetLastError();
+    return fail(nullptr, GREB_E_INVALID, "diffusion_batched_dev: T1_dev is not a device pointer of the current device");
+  }
   RowTables t; compute_row_tables(*p, p->kappa, nx, ny, t);
-  if (!tab_dev) { HIP_TRY0(dev_alloc(&tab_dev, 1)); std::memset(&tab_host, 0xff, sizeof(tab_host)); }
-  if (std::memcmp(&t, &tab_host, sizeof(t)) != 0) {
-    HIP_TRY0(hipMemcpy(tab_dev, &t, sizeof(t), hipMemcpyHostToDevice));
-    tab_host = t;
+  RowTables* tab_dev = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_tab_cache.mu);
+    TabCache::Entry& ce = g_tab_cache.by_device[dev];
+    if (!ce.dev) { HIP_TRY0(dev_alloc(&ce.dev, 1)); ce.valid = false; }
+    if (!ce.valid || std::memcmp(&t, &ce.host, sizeof(t)) != 0) {
+      HIP_TRY0(hipMemcpy(ce.dev, &t, sizeof(t), hipMemcpyHostToDevice));
+      ce.host = t; ce.valid = true;
+    }
+    tab_dev = ce.dev;
   }
   for (int i = 0; i < sweeps; ++i)
     HIP_TRY0(launch_diffusion(T1_dev, wz_dev, dX_dev, tab_dev, nx, ny, batch, strict != 0, (hipStream_t)stream));

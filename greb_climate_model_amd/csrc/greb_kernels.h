@@ -3,11 +3,25 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "greb_device.h"
 
 namespace greb {
 
 constexpr int kNT = 730;
+
+// Timing-experiment knobs (skip a family of tasks, shorten the sub-step loop, tile sizes) exist only in a
+// -DGREB_TUNING build (greb_climate_model_amd/build.py: build_lib(tuning=True) -> libgreb_hip_tuning.so, used by
+// tools/).  The release library never reads the environment: a stray variable cannot change the physics.
+#ifdef GREB_TUNING
+inline int tuning_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#else
+constexpr int tuning_int(const char*, int dflt) { return dflt; }
+#endif
 
 // Everything the fused member kernel needs (passed by value as a kernel argument).
 struct MemberArgs {

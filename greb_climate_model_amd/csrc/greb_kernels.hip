@@ -237,7 +237,7 @@ static int pick_band_rows(int nx, int ny, int halo, int extra_fields) {
   // whole field per workgroup when it fits ~44 KB (3+ workgroups share a CU's 160 KB); wide
   // grids get latitude bands of <= 64 KB
   size_t limit = nx <= 128 ? 44 * 1024 : 64 * 1024;
-  if (const char* e = getenv("GREB_BAND_LIMIT_KB")) limit = (size_t)atoi(e) * 1024; // tuning experiments
+  limit = (size_t)tuning_int("GREB_BAND_LIMIT_KB", (int)(limit / 1024)) * 1024; // -DGREB_TUNING builds only
   int rows = ny;
   while (rows > 2 && sweep_lds_bytes(nx, rows, halo, extra_fields) > limit) rows = (rows + 1) / 2;
   return rows;
@@ -264,18 +264,18 @@ static hipError_t launch_sweep(const float* T1, const float* wz, const float* u,
 
 hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const RowTables* tab_dev, int nx,
                             int ny, int batch, bool strict, hipStream_t s) {
-  static const bool no_stream = getenv("GREB_NO_STREAM") != nullptr; // A/B experiments
+  static const bool no_stream = tuning_int("GREB_NO_STREAM", 0) != 0; // -DGREB_TUNING builds only (A/B experiments)
   if (stream_fits(nx, ny) && !no_stream) {
     const size_t lds = stream_lds_bytes(nx, ny);
     auto kern = strict ? diffusion_stream_kernel<true, 96, 48> : diffusion_stream_kernel<false, 96, 48>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    static int wg_per_cu = getenv("GREB_STREAM_WGS") ? atoi(getenv("GREB_STREAM_WGS")) : 3;
+    static const int wg_per_cu = tuning_int("GREB_STREAM_WGS", 3);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = batch < cus * wg_per_cu ? batch : cus * wg_per_cu;
-    static const int dbg = getenv("GREB_DEBUG_SKIP") ? atoi(getenv("GREB_DEBUG_SKIP")) : 0; // timing experiments
+    static const int dbg = tuning_int("GREB_DEBUG_SKIP", 0); // -DGREB_TUNING builds only
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kStreamThreads), lds, s, T1, wz, dX, tab_dev, batch, dbg);
     return hipGetLastError();
   }
@@ -361,8 +361,11 @@ hipError_t launch_substep_fused(const float* X, const float* W2, const float* u,
 
 // PAIRS: X / Xout are [member][np][{Tair,q}] (the pair engine's layout) instead of [member][2][np]
 template <bool STRICT, bool FLUX, bool EXP, bool PAIRS>
-__global__ __launch_bounds__(256) void physics_step_kernel(MemberArgs a, const float* __restrict__ X,
-                                                           float* __restrict__ Xout, float* __restrict__ red) {
+// X and Xout may be the SAME buffer (run_year passes the current tracer buffer as both when the sub-step count is
+// even): every thread reads its own quad before it writes it and touches no other, so in-place is safe -- and the
+// pointers are therefore not __restrict__.
+__global__ __launch_bounds__(256) void physics_step_kernel(MemberArgs a, const float* X, float* Xout,
+                                                           float* __restrict__ red) {
   const int m = blockIdx.y, np = a.np;
   const int qd = blockIdx.x * blockDim.x + threadIdx.x;
   if (qd >= np / 4) return;

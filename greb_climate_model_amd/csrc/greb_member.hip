@@ -579,8 +579,8 @@ hipError_t launch_circulation_g96(const float* X, const float* wz, const float* 
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
   if (e != hipSuccess) return e;
-  const char* env = getenv("GREB_DEBUG_SKIP"); // timing experiments only
-  hipLaunchKernelGGL(kern, dim3(batch), dim3(kThreads), kLdsBytes, s, X, wz, u, v, dX, tab_dev, nsub, env ? atoi(env) : 0);
+  hipLaunchKernelGGL(kern, dim3(batch), dim3(kThreads), kLdsBytes, s, X, wz, u, v, dX, tab_dev, nsub,
+                     tuning_int("GREB_DEBUG_SKIP", 0)); // -DGREB_TUNING builds only
   return hipGetLastError();
 }
 

@@ -230,7 +230,7 @@ bool pair_sweep_supported(int nx, int ny) { return nx == kPairNx && ny >= 5 && n
 
 // rows per band: (rows+4) x 2 arrays x 3 KB + rows x 3 KB of winds + 6 KB of row constants; 4 rows = 67 KB, two workgroups per CU
 static int pair_band_rows() {
-  static const int r = getenv("GREB_PAIR_ROWS") ? atoi(getenv("GREB_PAIR_ROWS")) : 4; // tuning experiments
+  static const int r = tuning_int("GREB_PAIR_ROWS", 4); // -DGREB_TUNING builds only
   return r;
 }
 static size_t pair_lds_bytes(int rows) {

@@ -22,13 +22,25 @@ class GrebError(RuntimeError):
         self.code = code
 
 
+_lib_path = build.LIB
+
+
+def use_tuning_build() -> None:
+    """tools/ only: load libgreb_hip_tuning.so (-DGREB_TUNING, the build in which the GREB_DEBUG_* / tile-size
+    environment knobs exist) instead of the release library.  Must be called before the first engine call."""
+    global _lib_path
+    if _lib is not None:
+        raise GrebError(-100, "use_tuning_build() after the library was loaded")
+    _lib_path = build.LIB_TUNING
+
+
 def lib() -> C.CDLL:
     """Load libgreb_hip.so (never builds implicitly on the GPU box; fails loudly if absent)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(build.LIB):
-            raise GrebError(-100, f"{build.LIB} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
-        L = C.CDLL(build.LIB)
+        if not os.path.exists(_lib_path):
+            raise GrebError(-100, f"{_lib_path} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(_lib_path)
         L.greb_engine_last_error.restype = C.c_char_p
         L.greb_engine_last_error.argtypes = [C.c_void_p]
         L.greb_device_info.restype = C.c_char_p
@@ -42,7 +54,7 @@ EXPORTS = ["greb_params_default", "greb_engine_create", "greb_engine_flux_correc
            "greb_engine_last_error", "greb_engine_destroy", "greb_device_info", "greb_diffusion_batched",
            "greb_advection_batched", "greb_circulation_batched", "greb_diffusion_batched_dev",
            "greb_engine_point_physics", "greb_log_exp_switches", "greb_engine_set_experiment",
-           "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev", "greb_engine_set_state"]
+           "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev", "greb_engine_set_state", "greb_release_caches"]
 
 
 def _check(rc: int, h=None):
@@ -110,13 +122,21 @@ class Engine:
         _check(lib().greb_engine_flux_correction(self.h, int(years), abi.fptr(yearly)), self.h)
         return yearly[:, :years]
 
-    def run(self, years: int, co2_ppm, monthly_dev_ptr: int | None = None):
+    def run(self, years: int, co2_ppm, monthly_dev_ptr: int | None = None, out: np.ndarray | None = None):
         """co2_ppm: scalar, [years] or [n_members][years].  Returns (monthly, yearly); with
-        monthly_dev_ptr (a device address) the monthly means stay on the GPU and monthly is None."""
+        monthly_dev_ptr (a device address) the monthly means stay on the GPU and monthly is None.
+        out: caller-owned host buffer for the monthly means (float32, C-contiguous, n_members*years*12*5*np
+        elements -- e.g. the numpy view of a pinned torch tensor, which makes the delivery a true DMA)."""
         co2 = np.ascontiguousarray(np.broadcast_to(np.asarray(co2_ppm, np.float32), (self.nm, years)))
         yearly = np.zeros((self.nm, years, 2), np.float32)
         if monthly_dev_ptr is None:
-            monthly = np.empty((self.nm, years, 12, 5, self.ny, self.nx), np.float32)
+            shape = (self.nm, years, 12, 5, self.ny, self.nx)
+            if out is None:
+                monthly = np.empty(shape, np.float32)
+            else:
+                if out.dtype != np.float32 or not out.flags.c_contiguous or out.size != int(np.prod(shape)):
+                    raise GrebError(-1, "run: `out` must be C-contiguous float32 with n_members*years*12*5*ny*nx elements")
+                monthly = out.reshape(shape)
             _check(lib().greb_engine_run(self.h, int(years), abi.fptr(co2), abi.fptr(monthly), abi.fptr(yearly), 0), self.h)
             return monthly, yearly
         _check(lib().greb_engine_run(self.h, int(years), abi.fptr(co2), C.c_void_p(monthly_dev_ptr), abi.fptr(yearly),

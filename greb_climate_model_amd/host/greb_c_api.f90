@@ -13,6 +13,11 @@ module greb_c_api
      integer(c_int32_t) :: ipx, ipy, year0, dt, dt_crcl
   end type greb_params
 
+  ! per-member physics of a perturbed-physics ensemble; NaN = keep the engine-wide value
+  type, bind(C) :: greb_member_overrides
+     real(c_float) :: da_ice, a_no_ice, a_cloud, kappa
+  end type greb_member_overrides
+
   type, bind(C) :: greb_fields
      type(c_ptr) :: z_topo, glacier, sw_solar, tclim, qclim, uclim, vclim, mldclim, cldclim, swetclim
   end type greb_fields

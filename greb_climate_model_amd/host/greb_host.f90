@@ -13,15 +13,30 @@
 !   * the console trace                                (src/greb.f90:219,224-225,941,954,1070)
 ! Control crosses into the engine twice per run (flux-correction phase, scenario phase); the
 ! derived fields of greb_model's preamble are computed by the engine's create().
-! An optional fifth group &ENGINE_PAR (strict, device, corr_file) selects reference-order arithmetic,
-! the GPU, and a flux-correction cache file.  The interface module is host/greb_c_api.f90.
+! An optional fifth group &ENGINE_PAR (strict, device, corr_file, nx, ny) selects reference-order arithmetic,
+! the GPU, a flux-correction cache file and the grid (the reference's is compile-time, src/greb.f90:36).
+! An optional sixth group &ENSEMBLE_PAR runs an ENSEMBLE in one engine: in the reference an ensemble is N
+! processes with N namelists that differ in ens_id (src/greb.f90:153,1064-1068); here the N members share one
+! greb_engine_create call (the GPU integrates them side by side) and each member's monthly means go to its own
+! <output_file>_<ens_id> in the reference's record layout, so existing per-ens_id analysis scripts run unchanged:
+!   n_members            number of members (default 1 = the reference's single run)
+!   ens_ids(:)           their ids (default '001', '002', ...; with one member the &DIAGNOSTICS_PAR ens_id)
+!   co2_levels(:)        constant CO2 [ppm] per member, or
+!   co2_lo, co2_hi       a linear sweep over the members (BASELINE config 4: 280 .. 1120); neither given: every
+!                        member follows the &CO2_PAR series
+!   ens_da_ice(:), ens_a_no_ice(:), ens_a_cloud(:), ens_kappa(:)
+!                        per-member values of these &PHYSICS_PAR parameters (BASELINE config 5); unset = the
+!                        &PHYSICS_PAR value.  Members with their own physics get their own flux correction.
+! The interface module is host/greb_c_api.f90.
 
 program greb_host
   use iso_c_binding
   use greb_c_api
   implicit none
 
-  integer, parameter :: nx = 96, ny = 48, nstep = 730
+  integer, parameter :: nstep = 730, max_members = 4096
+  real, parameter :: unset = -999.
+  integer :: nx, ny
   ! ---- namelist variables under the reference's names
   real :: pi, sig, rho_ocean, rho_land, rho_air, cp_ocean, cp_land, cp_air, eps
   real :: d_ocean, d_land, d_air, ct_sens, da_ice, a_no_ice, a_cloud
@@ -43,7 +58,19 @@ program greb_host
   namelist / numerics_par / ipx, ipy, time_flux, time_scnr, year0
   namelist / diagnostics_par / output_file, ens_id
   namelist / co2_par / co2_ppm, co2_flux
-  namelist / engine_par / strict, device, corr_file
+  namelist / engine_par / strict, device, corr_file, nx, ny
+  ! ---- ensemble
+  integer :: n_members
+  character(len=10), allocatable :: ens_ids(:)
+  real, allocatable :: co2_levels(:), ens_da_ice(:), ens_a_no_ice(:), ens_a_cloud(:), ens_kappa(:)
+  real :: co2_lo, co2_hi
+  namelist / ensemble_par / n_members, ens_ids, co2_levels, co2_lo, co2_hi, ens_da_ice, ens_a_no_ice, ens_a_cloud, ens_kappa
+  type(greb_member_overrides), allocatable, target :: ov(:)
+  real(c_float), allocatable :: co2_all(:)
+  integer, allocatable :: units(:)
+  logical :: own_physics
+  integer :: m, y0, cy, chunk
+  integer(8) :: rec_year, moff
 
   type(greb_params) :: prm
   type(greb_fields) :: fld
@@ -71,7 +98,11 @@ program greb_host
   co2_flux = prm%co2_flux
   ipx = 1; ipy = 1; time_flux = 0; time_scnr = 0; year0 = 1940
   output_file = 'output/scenario'; ens_id = ''
-  strict = .false.; device = 0; corr_file = ''
+  strict = .false.; device = 0; corr_file = ''; nx = 96; ny = 48
+  n_members = 1; co2_lo = unset; co2_hi = unset
+  allocate(ens_ids(max_members), co2_levels(max_members), ens_da_ice(max_members), ens_a_no_ice(max_members), &
+       ens_a_cloud(max_members), ens_kappa(max_members))
+  ens_ids = ''; co2_levels = unset; ens_da_ice = unset; ens_a_no_ice = unset; ens_a_cloud = unset; ens_kappa = unset
 
   nargs = command_argument_count()
   nml_file = 'namelist'
@@ -84,7 +115,13 @@ program greb_host
   co2_ppm = -1.
   read(10, nml=co2_par)
   read(10, nml=engine_par, iostat=ios)   ! optional group
+  rewind(10)
+  read(10, nml=ensemble_par, iostat=ios) ! optional group
   close(10)
+  if (n_members < 1 .or. n_members > max_members) then
+     print*, 'greb_host: n_members must be 1 ..', max_members
+     error stop 1
+  end if
 
   ! a series shorter than the run is continued with its last value; none at all means 2xCO2
   if (co2_ppm(1) == -1.) co2_ppm(1) = 680.
@@ -98,7 +135,39 @@ program greb_host
      out_full = trim(output_file) // '_' // trim(ens_id)
   end if
 
-  print*,'% diagonstic point lat/lon: ',3.75*ipy-90, 3.75*ipx
+  print*,'% diagonstic point lat/lon: ',(180./ny)*ipy-90, (360./nx)*ipx
+
+  ! ---- the ensemble: ids, CO2 series [years, member] and physics overrides per member
+  do m = 1, n_members
+     if (len_trim(ens_ids(m)) == 0) then
+        if (n_members == 1) then
+           ens_ids(m) = ens_id
+        else
+           write(ens_ids(m), '(i3.3)') m
+        end if
+     end if
+  end do
+  allocate(co2_all(max(time_scnr,1)*n_members))
+  do m = 1, n_members
+     do i = 1, time_scnr
+        co2_all((m-1)*time_scnr + i) = co2_ppm(i)
+        if (co2_lo /= unset .and. co2_hi /= unset .and. n_members > 1) &
+             co2_all((m-1)*time_scnr + i) = real(dble(co2_lo) + dble(co2_hi - co2_lo)*dble(m-1)/dble(n_members-1))
+        if (co2_levels(m) /= unset) co2_all((m-1)*time_scnr + i) = co2_levels(m)
+     end do
+  end do
+  allocate(ov(n_members))
+  own_physics = .false.
+  do m = 1, n_members
+     ov(m)%da_ice = pick(ens_da_ice(m)); ov(m)%a_no_ice = pick(ens_a_no_ice(m))
+     ov(m)%a_cloud = pick(ens_a_cloud(m)); ov(m)%kappa = pick(ens_kappa(m))
+     if (ens_da_ice(m) /= unset .or. ens_a_no_ice(m) /= unset .or. ens_a_cloud(m) /= unset .or. ens_kappa(m) /= unset) &
+          own_physics = .true.
+  end do
+  if (own_physics .and. len_trim(corr_file) > 0) then
+     print*, 'greb_host: corr_file caches ONE flux correction; members with their own physics each have their own'
+     error stop 1
+  end if
 
   ! ---- boundary data
   allocate(z_topo(nx,ny), glacier(nx,ny), sw_solar(ny,nstep))
@@ -133,7 +202,11 @@ program greb_host
   flags = 0
   if (strict) flags = 1
   eng = c_null_ptr
-  rc = greb_engine_create(prm, nx, ny, fld, 1, c_null_ptr, int(device, c_int), flags, eng)
+  if (own_physics) then
+     rc = greb_engine_create(prm, int(nx, c_int), int(ny, c_int), fld, int(n_members, c_int), c_loc(ov), int(device, c_int), flags, eng)
+  else
+     rc = greb_engine_create(prm, int(nx, c_int), int(ny, c_int), fld, int(n_members, c_int), c_null_ptr, int(device, c_int), flags, eng)
+  end if
   call engine_check(rc, eng, 'greb_engine_create')
 
   ! Flux-correction cache (SURVEY.md 8f-2): the reference recomputes qflux_correction
@@ -157,12 +230,16 @@ program greb_host
      call engine_check(rc, eng, 'greb_engine_set_corrections')
   else
      print*,'% FLUX CORRECTION RUN; years = ', time_flux, ' co2 = ', co2_flux
-     allocate(yflux(2*max(time_flux,1)))
+     allocate(yflux(2*max(time_flux,1)*n_members))
      rc = greb_engine_flux_correction(eng, int(time_flux, c_int), yflux)
      call engine_check(rc, eng, 'greb_engine_flux_correction')
-     if (time_flux > 0) print *, 'console output: year, co2, global avg temp, avg temp for ipx/ipy'
-     do n = 1, time_flux
-        print *, 0.0, co2_flux, yflux(2*n-1), yflux(2*n)
+     do m = 1, n_members
+        if (m > 1 .and. .not. own_physics) exit   ! one shared flux correction: one trace
+        if (own_physics) print*, '% MEMBER ', trim(ens_ids(m))
+        if (time_flux > 0) print *, 'console output: year, co2, global avg temp, avg temp for ipx/ipy'
+        do n = 1, time_flux
+           print *, 0.0, co2_flux, yflux(2*((m-1)*time_flux + n)-1), yflux(2*((m-1)*time_flux + n))
+        end do
      end do
      if (len_trim(corr_file) > 0) then
         rc = greb_engine_get_corrections(eng, 0_c_int, corr, state5)
@@ -180,28 +257,65 @@ program greb_host
   end if
 
   print*,'% MODEL RUN; years = ', time_scnr
-  print*,'% saving output in file ', out_full
+  if (n_members == 1) print*,'% saving output in file ', out_full
+  if (n_members > 1) print*,'% saving output in files ', trim(output_file), '_<ens_id>; members = ', n_members
   if (time_scnr > 0) then
-     nrec = time_scnr*12*5
-     allocate(monthly(int(nrec,8)*nx*ny), yearly(2*time_scnr))
-     rc = greb_engine_run(eng, int(time_scnr, c_int), co2_ppm, monthly, yearly, 0_c_int)
-     call engine_check(rc, eng, 'greb_engine_run')
-     print *, 'console output: year, co2, global avg temp, avg temp for ipx/ipy'
-     year = year0
-     do n = 1, time_scnr
-        print *, year, co2_ppm(n), yearly(2*n-1), yearly(2*n)
-        year = year + 1
+     ! the engine's clock continues across calls (include/greb_engine.h), so a long run is taken in chunks of whole
+     ! years that keep the monthly-mean buffer [member][year][12][5][ny][nx] below ~2 GB
+     rec_year = int(12*5, 8)*nx*ny
+     chunk = int(max(1_8, min(int(time_scnr, 8), 500000000_8/(rec_year*n_members))))
+     allocate(monthly(rec_year*chunk*n_members), yearly(2*time_scnr*n_members), units(n_members))
+     do m = 1, n_members
+        if (n_members == 1) then
+           open(newunit=units(m), file=out_full, access='direct', form='unformatted', recl=4*nx*ny)
+        else
+           open(newunit=units(m), file=trim(output_file)//'_'//trim(ens_ids(m)), access='direct', form='unformatted', recl=4*nx*ny)
+        end if
      end do
-     open(22, file=out_full, access='direct', form='unformatted', recl=4*nx*ny)
-     do irec = 1, nrec
-        off = int(irec-1, 8)*nx*ny
-        write(22, rec=irec) monthly(off+1:off+nx*ny)
+     do y0 = 0, time_scnr - 1, chunk
+        cy = min(chunk, time_scnr - y0)
+        rc = greb_engine_run(eng, int(cy, c_int), chunk_co2(y0, cy), monthly, yearly(2*y0*n_members+1:), 0_c_int)
+        call engine_check(rc, eng, 'greb_engine_run')
+        do m = 1, n_members
+           moff = int(m-1, 8)*cy*rec_year
+           do irec = 1, cy*60
+              off = moff + int(irec-1, 8)*nx*ny
+              write(units(m), rec=y0*60 + irec) monthly(off+1:off+nx*ny)   ! :978-982
+           end do
+        end do
      end do
-     close(22)
+     do m = 1, n_members
+        close(units(m))
+        if (n_members > 1) print*, '% MEMBER ', trim(ens_ids(m))
+        print *, 'console output: year, co2, global avg temp, avg temp for ipx/ipy'
+        year = year0
+        do n = 1, time_scnr
+           ! yearly holds one [member][cy][2] block per chunk
+           y0 = ((n-1)/chunk)*chunk; cy = min(chunk, time_scnr - y0)
+           i = 2*y0*n_members + 2*((m-1)*cy + (n-1-y0))
+           print *, year, co2_all((m-1)*time_scnr + n), yearly(i+1), yearly(i+2)
+           year = year + 1
+        end do
+     end do
   end if
   rc = greb_engine_destroy(eng)
 
 contains
+  real(c_float) function pick(v)
+    use ieee_arithmetic
+    real, intent(in) :: v
+    pick = v
+    if (v == unset) pick = ieee_value(1.0_c_float, ieee_quiet_nan)   ! NaN = keep the engine-wide value
+  end function
+  function chunk_co2(y0, cy) result(c)
+    ! [member][cy] slice of the [member][time_scnr] series
+    integer, intent(in) :: y0, cy
+    real(c_float) :: c(cy*n_members)
+    integer :: mm
+    do mm = 1, n_members
+       c((mm-1)*cy+1 : mm*cy) = co2_all((mm-1)*time_scnr + y0 + 1 : (mm-1)*time_scnr + y0 + cy)
+    end do
+  end function
   subroutine read_records(fname, a, nrecs)
     character(*), intent(in) :: fname
     integer, intent(in) :: nrecs

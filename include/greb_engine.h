@@ -170,6 +170,9 @@ int greb_circulation_batched(const greb_params* p, int nx, int ny, int batch, co
 int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, const float* T1_dev,
                                const float* wz_dev, float* dX_dev, int strict, int sweeps,
                                void* stream);
+/* greb_diffusion_batched_dev keeps one small row-constant table per device between calls (so that back-to-back
+ * sweeps are not separated by an allocation); a long-lived host releases them with this.  Engines are unaffected. */
+int greb_release_caches(void);
 
 /* Point physics of one step for a batch of columns sets (tests): SWradiation :367-403,
  * LWradiation :407-434, hydro :438-469, deep_ocean :495-525, seaice :472-492 evaluated by the

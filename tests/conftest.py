@@ -49,3 +49,17 @@ def routine_golden():
 def rms(a, b):
     d = np.asarray(a, np.float64) - np.asarray(b, np.float64)
     return float(np.sqrt(np.mean(d * d)))
+
+
+def yearly_close(got, ref, strict=False, npoints=4608):
+    """The console values of src/greb.f90:954: [..., 0] = global-mean Tsurf, [..., 1] = Tsurf at (ipx, ipy), deg C.
+    The point value is one fp32 number: 1e-4 K = 3 ulp at 285 K.  The global mean is `sum(tsmn)/(xdim*ydim)`, which
+    the reference evaluates as a SEQUENTIAL fp32 sum of 4608 (73 728) values of ~280 K: partial sums reach 1.3e6
+    (ulp 0.125), so the reference's own printed mean carries a rounding error of a few 1e-4 K.  STRICT arithmetic
+    sums in the same order (2e-4: only the libm-level differences of the run remain); FAST sums by per-lane partials
+    + wavefront shuffle reduction, which is closer to the exact mean than the reference's value is -- 1e-3 at
+    96x48; the sequential sum's error grows like sqrt(n) * ulp(sum) / n ~ sqrt(n), so 4e-3 at 384x192."""
+    d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
+    assert d[..., 1].max() < 1e-4, ("point value", d[..., 1].max())
+    tol = 2e-4 if strict else 1e-3 * max(1.0, (npoints / 4608.0) ** 0.5)
+    assert d[..., 0].max() < tol, ("global mean", d[..., 0].max(), tol)

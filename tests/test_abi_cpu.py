@@ -75,3 +75,16 @@ def test_product_does_not_touch_oracle():
     import subprocess
     out = subprocess.run(["ldd", build.LIB], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_release_library_never_reads_the_environment(lib):
+    """Timing-experiment knobs (GREB_DEBUG_SKIP, GREB_DEBUG_NSUB, tile sizes) are compiled in only under
+    -DGREB_TUNING (libgreb_hip_tuning.so, tools/): the release library does not import getenv at all, so a stray
+    variable cannot change the physics."""
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    raw = open(build.LIB, "rb").read()
+    for knob in (b"GREB_DEBUG_SKIP", b"GREB_DEBUG_NSUB", b"GREB_BAND_LIMIT_KB", b"GREB_NO_STREAM", b"GREB_STREAM_WGS",
+                 b"GREB_PAIR_ROWS"):
+        assert knob not in raw, knob

@@ -5,7 +5,7 @@ embedded in a full batch, monotone CO2 response)."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, rms
+from conftest import load_golden, rms, yearly_close
 
 pytestmark = pytest.mark.gpu
 TOL = (1e-4, 1e-4, 1e-4, 2e-8, 1e-6)  # Tsurf, Tair, Tocean [K], q, albedo: RMS of a monthly-mean field
@@ -30,7 +30,7 @@ def test_config2_default_namelist_3_plus_50_years(inputs, params):
         assert np.abs(means[:, i] - g["stats"][:, i, 0]).max() < tol, i
         assert np.abs(mon[:, i].min((1, 2)) - g["stats"][:, i, 1]).max() < 30 * tol, i
         assert np.abs(mon[:, i].max((1, 2)) - g["stats"][:, i, 2]).max() < 30 * tol, i
-    assert np.abs(np.concatenate([yf[0], yr[0]]) - g["yearly"]).max() < 2e-3  # console values (fp32 sum of 4608)
+    yearly_close(np.concatenate([yf[0], yr[0]]), g["yearly"])
 
 
 def test_full_batch_512_members_known_answers_and_replicas(inputs, params):
@@ -57,7 +57,7 @@ def test_full_batch_512_members_known_answers_and_replicas(inputs, params):
         got = ref.cpu().numpy().reshape(5, 48, 96)
         for i, tol in enumerate(TOL):
             assert rms(got[i], g["december"][lv][i]) < tol, (lv, i)
-        assert np.abs(yr[ids[0]] - g["yearly"][lv][1:]).max() < 2e-3
+        yearly_close(yr[ids[0]], g["yearly"][lv][1:])
     first = [int(np.nonzero(level == lv)[0][0]) for lv in range(8)]
     assert np.all(np.diff(yr[first, -1, 0]) > 0)  # warmer with more CO2
 

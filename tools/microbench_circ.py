@@ -6,6 +6,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from greb_climate_model_amd import engine, workload, abi
+engine.use_tuning_build()  # GREB_DEBUG_* knobs exist only in the -DGREB_TUNING library
 
 nsub = int(sys.argv[1]) if len(sys.argv) > 1 else 2400
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
