@@ -132,6 +132,7 @@ struct greb_engine {
   // model clock
   long long it_flux = 0; // steps done in the flux phase
   long long it_scnr = 0; // steps done in the scenario
+  unsigned long long* stamps = nullptr; // -DGREB_TUNING builds only: device buffer for the member kernel's stamps
   std::string last_error;
 };
 
@@ -161,6 +162,7 @@ MemberArgs base_args(greb_engine* e) {
   a.co2_flux = e->p.co2_flux;
   a.ipx = e->p.ipx; a.ipy = e->p.ipy;
   a.xsw = e->xsw;
+  a.stamps = e->stamps;
   if (e->xsw & GREB_X_NO_CIRCULATION) a.nsub = 0; // no transport at all: the tracers come back unchanged
   return a;
 }
@@ -585,6 +587,16 @@ struct TabCache {
   std::map<int, Entry> by_device;
 } g_tab_cache;
 } // namespace
+
+#ifdef GREB_TUNING
+// diagnostic builds only (not part of include/greb_engine.h): where the fused member kernel writes its stamps,
+// [n_members][8 waves][8] unsigned long long on the device (tools/stamp_member.py); NULL switches them off
+int greb_tuning_set_stamps(greb_engine* e, unsigned long long* stamps_dev) {
+  if (!e) return GREB_E_INVALID;
+  e->stamps = stamps_dev;
+  return 0;
+}
+#endif
 
 int greb_release_caches(void) {
   std::lock_guard<std::mutex> lock(g_tab_cache.mu);

@@ -54,6 +54,9 @@ struct MemberArgs {
   int yearly_years, yearly_year0;
   int ipx, ipy;          // 1-based
   unsigned xsw;          // experiment switches (kX*, greb_device.h); 0 = complete model
+  // -DGREB_TUNING builds only (null otherwise; the release kernels contain no stamp code): per member and wave, 8
+  // cycle totals of one launch -- see tools/stamp_member.py
+  unsigned long long* stamps;
 };
 
 // fused engine (greb_member.hip): 96x48 with the default sub-cycling layout -- rows 0-9 and 38-47

@@ -259,7 +259,7 @@ struct BulkTasks { TaskAddr t[3]; };
 // worst the other way round.
 // bulk slot s = 0..5 of the schedules below: slots 0, 1 -> waves 0, 1; slots 2, 3 (the SIMDs that also carry a
 // polar wave) -> waves 6, 7; slots 4, 5 -> waves 4, 5.
-__device__ __forceinline__ int bulk_slot(int wave) { return wave >= 6 ? wave - 4 : wave; }
+__host__ __device__ constexpr int bulk_slot(int wave) { return wave >= 6 ? wave - 4 : wave; }
 
 // The schedule (both arithmetic modes).  Task kinds: one row (S1 sub-cycled family, F1 full family) or two stacked rows (ST, FT).
 //   ST  rows (1,2) (3,4) (5,6) (7,8) (39,40) .. (45,46) : 8 pairs x 24 quads = 3 full passes
@@ -272,7 +272,7 @@ __device__ __forceinline__ int bulk_slot(int wave) { return wave >= 6 ? wave - 4
 //                            w2: FT1 F1_3 (+ pole)          (SIMD 2: 579 + 800)
 //                            w3: FT2 F1_4 (+ pole)          (SIMD 3: 579 + 800)
 enum { kNone = 0, kS1 = 1, kF1 = 2, kST = 3, kFT = 4 };
-__device__ __forceinline__ int fast_kind(int wave, int i) {
+__host__ __device__ constexpr int fast_kind(int wave, int i) {
   switch (wave) {
     case 0: return i == 0 ? kST : (i == 1 ? kFT : kNone);
     case 4: return i == 0 ? kST : kNone;
@@ -282,7 +282,7 @@ __device__ __forceinline__ int fast_kind(int wave, int i) {
   }
   return kNone;
 }
-__device__ __forceinline__ int fast_index(int wave, int i) { // which pass of its kind
+__host__ __device__ constexpr int fast_index(int wave, int i) { // which pass of its kind
   switch (wave) {
     case 0: return 0;                    // ST0, FT0
     case 4: return 1;                    // ST1
@@ -292,6 +292,13 @@ __device__ __forceinline__ int fast_index(int wave, int i) { // which pass of it
     case 3: return i == 0 ? 2 : 4;       // FT2, F1_4
   }
   return 0;
+}
+
+// number of tasks of a pass: 64 = every lane has one
+__host__ __device__ constexpr int pass_tasks(int kind, int index) {
+  const int total = kind == kST || kind == kFT ? 8 * NQ : (kind == kS1 ? 2 * NQ : (kind == kF1 ? 12 * NQ : 0));
+  const int left = total - 64 * index;
+  return left >= 64 ? 64 : (left > 0 ? left : 0);
 }
 
 // once per launch; the asm makes the values opaque, so the compiler keeps them instead of re-deriving them from
@@ -323,17 +330,25 @@ __device__ __forceinline__ BulkTasks make_tasks(int wave, int lane) {
   return b;
 }
 
-template <bool STRICT>
-__device__ __forceinline__ void bulk_substep(lfloat* lds, int cur, int wave, const BulkTasks& tasks, int dbg, bool calm_q = false) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int kind = __builtin_amdgcn_readfirstlane(fast_kind(wave, i));
-    if (kind == kNone || tasks.t[i].kq < 0) continue;
-    if (kind == kS1) { if (!(dbg & 1)) row_task<STRICT, true>(lds, cur, tasks.t[i], calm_q); }
-    else if (kind == kF1) { if (!(dbg & 2)) row_task<STRICT, false>(lds, cur, tasks.t[i], calm_q); }
-    else if (kind == kST) { if (!(dbg & 1)) row_task2<STRICT, true>(lds, cur, tasks.t[i], calm_q); }
-    else { if (!(dbg & 2)) row_task2<STRICT, false>(lds, cur, tasks.t[i], calm_q); }
+// task i of bulk slot SLOT: kind and pass are compile-time, so a wave's sub-step is straight-line code -- no
+// per-sub-step dispatch on the wave number (that dispatch, a switch on a VGPR lowered to exec-mask bookkeeping, cost
+// every bulk wave ~100 issue slots per sub-step)
+template <bool STRICT, int SLOT, int I>
+__device__ __forceinline__ void bulk_task(lfloat* lds, int cur, const BulkTasks& tasks, int dbg, bool calm_q) {
+  constexpr int kind = fast_kind(SLOT, I), ntask = pass_tasks(kind, fast_index(SLOT, I));
+  if constexpr (kind != kNone && ntask > 0) {
+    if (ntask < 64 && tasks.t[I].kq < 0) return; // partial pass: lanes without a task
+    if constexpr (kind == kS1) { if (!(dbg & 1)) row_task<STRICT, true>(lds, cur, tasks.t[I], calm_q); }
+    else if constexpr (kind == kF1) { if (!(dbg & 2)) row_task<STRICT, false>(lds, cur, tasks.t[I], calm_q); }
+    else if constexpr (kind == kST) { if (!(dbg & 1)) row_task2<STRICT, true>(lds, cur, tasks.t[I], calm_q); }
+    else { if (!(dbg & 2)) row_task2<STRICT, false>(lds, cur, tasks.t[I], calm_q); }
   }
+}
+template <bool STRICT, int SLOT>
+__device__ __forceinline__ void bulk_substep(lfloat* lds, int cur, const BulkTasks& tasks, int dbg, bool calm_q = false) {
+  bulk_task<STRICT, SLOT, 0>(lds, cur, tasks, dbg, calm_q);
+  bulk_task<STRICT, SLOT, 1>(lds, cur, tasks, dbg, calm_q);
+  bulk_task<STRICT, SLOT, 2>(lds, cur, tasks, dbg, calm_q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -529,11 +544,48 @@ struct Circ {
       st8(lds + kOffW + (i / NQ) * RS, i % NQ, zip(ld4(wz_air + 4 * i), ld4(wz_vapor + 4 * i)));
   }
 
-  // dbg: timing experiments only (tools/microbench_circ.py): bit0/1/2 skip sub / full / chain work
-  __device__ __forceinline__ void substep(lfloat* lds, int cur, int dbg = 0, bool calm_q = false) {
-    const int wave = threadIdx.x >> 6;
-    if (wave == 2 || wave == 3) { if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, wave - 2, calm_q); }
-    else bulk_substep<STRICT>(lds, cur, bulk_slot(wave), tasks, dbg, calm_q);
+  // One wave's share of `nsub` sub-steps, one s_barrier after each (every wave of the workgroup executes the same
+  // number of barriers, each in its own loop).  WAVE is compile-time: the loop body is the wave's own straight-line
+  // task sequence.  dbg: timing experiments only (tools/microbench_circ.py): bit0/1/2 skip sub / full / chain work.
+  template <int WAVE>
+  __device__ __forceinline__ void role_loop(lfloat* lds, int cur, int nsub, int dbg, bool calm_q
+#ifdef GREB_TUNING
+                                            , bool stamp, unsigned long long& busy
+#endif
+  ) {
+#pragma unroll 1
+    for (int tt = 0; tt < nsub; ++tt) {
+#ifdef GREB_TUNING
+      const unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+      if constexpr (WAVE == 2 || WAVE == 3) { if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, WAVE - 2, calm_q); }
+      else bulk_substep<STRICT, bulk_slot(WAVE)>(lds, cur, tasks, dbg, calm_q);
+#ifdef GREB_TUNING
+      if (stamp) busy += __builtin_amdgcn_s_memtime() - t0;
+#endif
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // `nsub` sub-steps starting from buffer `cur`; the caller continues with buffer cur ^ (nsub & 1)
+  __device__ __forceinline__ void substeps(lfloat* lds, int cur, int nsub, int dbg = 0, bool calm_q = false
+#ifdef GREB_TUNING
+                                           , bool stamp = false, unsigned long long* busy = nullptr
+#endif
+  ) {
+#ifdef GREB_TUNING
+    unsigned long long b = 0;
+#define GREB_ROLE(W) case W: role_loop<W>(lds, cur, nsub, dbg, calm_q, stamp, b); break;
+#else
+#define GREB_ROLE(W) case W: role_loop<W>(lds, cur, nsub, dbg, calm_q); break;
+#endif
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) { // a scalar branch per circulation call
+      GREB_ROLE(0) GREB_ROLE(1) GREB_ROLE(2) GREB_ROLE(3) GREB_ROLE(4) GREB_ROLE(5) GREB_ROLE(6) GREB_ROLE(7)
+    }
+#undef GREB_ROLE
+#ifdef GREB_TUNING
+    if (busy) *busy += b;
+#endif
   }
 };
 
@@ -560,13 +612,8 @@ __global__ __launch_bounds__(kThreads) void circulation_g96_kernel(const float* 
   }
   stage_winds<STRICT>(lds, ug + fo, vg + fo, tab);
   __syncthreads();
-  int cur = 0;
-#pragma unroll 1
-  for (int tt = 0; tt < nsub; ++tt) {
-    c.substep(lds, cur, dbg);
-    __syncthreads();
-    cur ^= 1;
-  }
+  c.substeps(lds, 0, nsub, dbg);
+  const int cur = nsub & 1;
   for (int i = threadIdx.x; i < NP / 4; i += kThreads) {
     const f4 a = comp(ld8(lds + kOffX + cur * XB + (i / NQ) * RS, i % NQ), 0), b = ld4(Xin + fo + 4 * i);
     st4(dX + fo + 4 * i, f4{{a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2], a.v[3] - b.v[3]}}); // :551
@@ -604,6 +651,17 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     st8(lds + kOffX + (i / NQ) * RS, i % NQ, zip(ld4(state + NP + 4 * i), ld4(state + 3 * NP + 4 * i))); // (Tair, q)
   int cur = 0;
   __syncthreads();
+#ifdef GREB_TUNING
+  // diagnostic stamps (tools/stamp_member.py): shader-clock cycles this wave spent in each phase of the launch, its
+  // busy time inside the sub-steps (barrier release -> arrival at the next barrier) and the launch's wall time in
+  // s_memrealtime ticks (100 MHz) -- in-kernel clock = cycles / ticks x 100 MHz
+  const bool stamp = a.stamps != nullptr;
+  unsigned long long st_wind = 0, st_circ = 0, st_busy = 0, st_phys = 0;
+  const unsigned long long st_c0 = stamp ? __builtin_amdgcn_s_memtime() : 0, st_r0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
+#define GREB_STAMP(var) const unsigned long long var = stamp ? __builtin_amdgcn_s_memtime() : 0
+#else
+#define GREB_STAMP(var)
+#endif
 
 #pragma unroll 1
   for (int s = 0; s < a.nsteps; ++s) {
@@ -612,16 +670,19 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     const int ityr = ck.ityr, yr_rel = ck.yr_rel;
     const size_t off = ck.off;
 
+    GREB_STAMP(t_a);
     stage_winds<STRICT>(lds, a.uclim + off, a.vclim + off, tab);
     __syncthreads();
+    GREB_STAMP(t_b);
 
     // ---- circulation of Tair and q: 24 sub-steps (:543-550)
-#pragma unroll 1
-    for (int tt = 0; tt < a.nsub; ++tt) {
-      circ.substep(lds, cur, 0, EXP && (a.xsw & kXQDiffOnly));
-      __syncthreads();
-      cur ^= 1;
-    }
+#ifdef GREB_TUNING
+    circ.substeps(lds, cur, a.nsub, 0, EXP && (a.xsw & kXQDiffOnly), stamp, &st_busy);
+#else
+    circ.substeps(lds, cur, a.nsub, 0, EXP && (a.xsw & kXQDiffOnly));
+#endif
+    cur ^= a.nsub & 1;
+    GREB_STAMP(t_c);
 
     // ---- point physics on the OLD state + Euler update (:254-268 / :328-361)
     const Phys P = a.phys[m];
@@ -668,7 +729,20 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
       }
     }
     __syncthreads();
+#ifdef GREB_TUNING
+    if (stamp) {
+      const unsigned long long t_d = __builtin_amdgcn_s_memtime();
+      st_wind += t_b - t_a; st_circ += t_c - t_b; st_phys += t_d - t_c;
+    }
+#endif
   }
+#ifdef GREB_TUNING
+  if (stamp && (tid & 63) == 0) {
+    unsigned long long* o = a.stamps + ((size_t)m * (kThreads / 64) + (tid >> 6)) * 8;
+    o[0] = __builtin_amdgcn_s_memtime() - st_c0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    o[2] = st_wind; o[3] = st_circ; o[4] = st_busy; o[5] = st_phys; o[6] = (unsigned long long)a.nsteps; o[7] = (unsigned long long)a.nsub;
+  }
+#endif
   // all five state fields were written back every step
 }
 

@@ -111,6 +111,16 @@ def make_inputs(nx: int = 96, ny: int = 48, basis: dict | None = None) -> Inputs
                   swetclim=swet, meta={"basis": os.path.basename(BASIS_PATH)})
 
 
+def routine_inputs_g384(inp: Inputs):
+    """The (Tair, q, ityr) the 384x192 per-routine golden vectors were minted on (tests/golden/routine_g384.npz):
+    climatology slices of step 400 displaced by a tenth of the seasonal difference, fp32 arithmetic only."""
+    ityr = 400
+    Ts = inp.tclim[ityr - 1]
+    Ta = (Ts + f32(0.1) * (inp.tclim[99] - inp.tclim[499])).astype(f32)
+    q = (inp.qclim[ityr - 1] * f32(0.95)).astype(f32)
+    return Ta, q, ityr
+
+
 def write_namelist(path: str, time_flux: int, time_scnr: int, co2_ppm=(680.0,), ipx: int = 95,
                    ipy: int = 38, output_file: str = "output/scenario", ens_id: str = "",
                    physics: dict | None = None, co2_flux: float | None = None,

@@ -23,6 +23,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle_greb.so")
 REF_SO = os.path.join(HERE, "_ref", "libgreb_ref.so")
 REF_BIN = os.path.join(HERE, "_ref", "greb_ref")
+REF384_SO = os.path.join(HERE, "_ref", "libgreb_ref384.so")  # `make ref384`: the reference with xdim = 384, ydim = 192
+REF384_BIN = os.path.join(HERE, "_ref", "greb_ref384")
 ORIG_BIN = os.path.join(HERE, "_ref", "greb_orig")  # the upstream variant with the log_exp switches
 NT = 730
 fp = abi.fptr
@@ -203,13 +205,14 @@ class RefLib:
         """Module state is set from `inp` plus the derived fields of greb_model's preamble
         (src/greb.f90:176-216), which are taken from `oracle` (they are inputs here; the
         preamble itself is pinned by the whole-run comparison)."""
-        assert (inp.nx, inp.ny) == (96, 48), "reference grid is compile-time 96x48 (src/greb.f90:36)"
-        self.lib = L = C.CDLL(REF_SO)
-        self.nx, self.ny, self.np = 96, 48, 96 * 48
+        # the reference's grid is compile-time (src/greb.f90:36): one library per grid
+        assert (inp.nx, inp.ny) in ((96, 48), (384, 192)), "no reference build for this grid"
+        self.lib = L = C.CDLL(REF_SO if inp.nx == 96 else REF384_SO)
+        self.nx, self.ny, self.np = inp.nx, inp.ny, inp.nx * inp.ny
         self.inp = inp
         self.g2("z_topo")[:] = inp.z_topo
         self.g2("glacier")[:] = inp.glacier
-        self.g("sw_solar", (NT, 48))[:] = inp.sw_solar
+        self.g("sw_solar", (NT, self.ny))[:] = inp.sw_solar
         for name, src in (("tclim", inp.tclim), ("uclim", inp.uclim), ("vclim", inp.vclim), ("qclim", inp.qclim),
                           ("mldclim", inp.mldclim), ("cldclim", inp.cldclim), ("swetclim", inp.swetclim)):
             self.g3(name)[:] = src
@@ -239,10 +242,10 @@ class RefLib:
         return np.ctypeslib.as_array(arr).reshape(shape)
 
     def g2(self, name, mod="mo_physics"):
-        return self.g(name, (48, 96), mod)
+        return self.g(name, (self.ny, self.nx), mod)
 
     def g3(self, name):
-        return self.g(name, (NT, 48, 96))
+        return self.g(name, (NT, self.ny, self.nx))
 
     def scalar(self, name, ctype=C.c_float, mod="mo_physics"):
         return ctype.in_dll(self.lib, f"_QM{mod}E{name}")
@@ -257,7 +260,7 @@ class RefLib:
         return out
 
     def _f(self):
-        return np.empty((48, 96), np.float32)
+        return np.empty((self.ny, self.nx), np.float32)
 
     def diffusion(self, T1, wz):
         T1, wz = np.ascontiguousarray(T1, np.float32), np.ascontiguousarray(wz, np.float32)

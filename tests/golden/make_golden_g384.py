@@ -9,6 +9,10 @@ C restatement (oracle/greb_oracle.c) reproduces its output BIT FOR BIT -- includ
 reference's integer dtdff2 is 0 (src/greb.f90:652-654: NINT(Inf); the flang x86-64 build yields one sweep with
 ccx2 = 0) and the rows with up to 225 dependent diffusion sweeps.
 
+  routine_g384.npz   one call each of diffusion / advection / circulation (src/greb.f90:556-915) on (Tair, wz_air) and
+                     (q, wz_vapor) at ityr = 400 through oracle/_ref/libgreb_ref384.so, default kappa, plus diffusion and
+                     circulation of Tair at kappa = 7.2e5 (1 800 sweeps in the two polar rows).  Inputs are
+                     regenerated from the workload in fp32 (routine_inputs_g384), only the outputs are stored.
   g384_short.npz     BASELINE config 3 in miniature: default physics, 1+2 yr, 2xCO2.  Months 1, 12, 24 in full,
                      every month's zonal means, eight polar rows and field statistics, the console scalars.
   g384_physpar.npz   BASELINE config 5 in miniature: four perturbed-physics members (da_ice, a_no_ice, a_cloud,
@@ -52,6 +56,8 @@ def _unlimit_stack():
 def run_ref384(wd, time_flux, time_scnr, co2, physics=None):
     """./greb in `wd` (its input/ already written): returns (monthly [months][5][ny][nx], stdout, wall s)."""
     os.makedirs(os.path.join(wd, "output"), exist_ok=True)
+    if os.path.exists(os.path.join(wd, "output", "scenario")):  # direct-access files are not truncated by a shorter run
+        os.remove(os.path.join(wd, "output", "scenario"))
     workload.write_namelist(os.path.join(wd, "namelist"), time_flux, time_scnr, (co2,), 95 * 4, 38 * 4, physics=physics)
     t0 = time.time()
     r = subprocess.run([REF384], cwd=wd, capture_output=True, text=True, check=True, preexec_fn=_unlimit_stack)
@@ -70,12 +76,47 @@ def month_hashes(mon):
     return [hashlib.sha256(np.ascontiguousarray(mon[i]).tobytes()).hexdigest() for i in range(mon.shape[0])]
 
 
+def routines(inp, manifest):
+    out, all_eq = {}, True
+    for tag, kappa in (("", None), ("_k72", 7.2e5)):
+        p = abi.default_params()
+        if kappa is not None:
+            p.kappa = kappa
+        orc = O.Oracle(inp, p)
+        ref = O.RefLib(inp, orc)
+        ref.scalar("kappa").value = p.kappa
+        Ta, q, ityr = workload.routine_inputs_g384(inp)
+        wa, wv = orc.field(5).copy(), orc.field(6).copy()
+        calls = [("dif_Ta", lambda L: L.diffusion(Ta, wa)), ("crc_Ta", lambda L: L.circulation(ityr, Ta, wa) if L is ref else L.circulation(Ta, wa, ityr=ityr))]
+        if kappa is None:
+            calls += [("dif_q", lambda L: L.diffusion(q, wv)),
+                      ("adv_Ta", lambda L: L.advection(ityr, Ta, wa) if L is ref else L.advection(Ta, wa, ityr=ityr)),
+                      ("adv_q", lambda L: L.advection(ityr, q, wv) if L is ref else L.advection(q, wv, ityr=ityr)),
+                      ("crc_q", lambda L: L.circulation(ityr, q, wv) if L is ref else L.circulation(q, wv, ityr=ityr))]
+        for name, fn in calls:
+            r, o = fn(ref), fn(orc)
+            eq = bool(np.array_equal(r, o))
+            all_eq &= eq
+            print(f"routine_g384 {name}{tag}: oracle bit-identical to reference: {eq}", flush=True)
+            assert eq and np.isfinite(r).all()
+            out[name + tag] = r
+        if kappa is not None:
+            g = orc.grid()
+            assert int(g["dif_time2"][0]) == 1800 and int(g["dif_time2"][-1]) == 1800
+        orc.close()
+        del ref
+    np.savez_compressed(os.path.join(OUT, "routine_g384.npz"), **out)
+    manifest["items"]["routine_g384"] = {"grid": [NX, NY], "ityr": 400, "oracle_bit_identical": all_eq,
+                                         "fields": sorted(out)}
+
+
 def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref384"], check=True)
     assert os.path.exists(REF384), REF384
     mpath = os.path.join(OUT, "MANIFEST.json")
     manifest = json.load(open(mpath))
     inp = workload.make_inputs(NX, NY)
+    routines(inp, manifest)
     wd = tempfile.mkdtemp(prefix="greb_ref384_", dir="/tmp")
     try:
         inp.write_input_dir(os.path.join(wd, "input"))  # 1.5 GB, shared by every run below
