@@ -40,7 +40,13 @@ namespace greb {
 
 constexpr int NX = 96, NY = 48, NQ = 24, NP = 4608;
 constexpr int kThreads = 512;
-constexpr int RS = 2 * NX; // floats per interleaved row
+// floats per interleaved row: 2*NX = 192 data + 16 of padding, i.e. a row stride of 52 sixteen-byte slots = 4 mod 16.
+// A ds_read_b128 is served in groups of 16 lanes that must hit 16 different slot classes (slot mod 16) to take one
+// LDS cycle.  With the unpadded stride (48 slots = 0 mod 16) every row started in the same class and the lanes of a
+// pass, which span two to three rows, collided two-way on every read (42 % of the LDS cycles of the round-1 kernel
+// were bank conflicts); with 4 mod 16, rows two apart -- the neighbouring row pairs of a pass -- are offset by 8
+// classes and the 16 lanes of every group fall on distinct classes.
+constexpr int RS = 2 * NX + 16;
 // LDS map, in floats
 // X buffers and W carry one all-zero GUARD row below row 0 and above row NY-1: the rows k-2 .. k+2 of any bulk
 // row are then five rows at constant strides from ONE base address (immediate offsets of the ds_read), and the
@@ -50,8 +56,11 @@ constexpr int kOffX = RS;           // row 0 of X[0]; X[b] row k at kOffX + b*XB
 constexpr int kOffW = 2 * XB + RS;  // row 0 of W  [NY][NX][{wz_air,wz_vapor}]
 constexpr int kOffWX = 3 * XB;      // [NP]  cu*u   (raw u in rows 0, 47 and in STRICT)
 constexpr int kOffWY = kOffWX + NP; // [NP]  ccy/3*v (raw v ...)
-constexpr int kOffScr = kOffWY + NP; // [2 poles][2][RS]
-constexpr int kOffRowK = kOffScr + 4 * RS; // [NY][kRowKWords]
+constexpr int kOffRowK = kOffWY + NP; // [NY][kRowKWords]
+// The Jacobi row buffers of the polar chains live in the GUARD rows of the two X buffers (pole 0: the lower guards,
+// pole 1: the upper ones).  A guard row's content only ever meets a zero weight (W's guard rows stay zero) or, in
+// STRICT, is loaded and not used, so any finite value may sit there; this is what pays for the row padding.
+__device__ __forceinline__ int pole_buf(int pole, int which) { return which * XB + pole * (NY + 1) * RS; }
 constexpr int kLdsFloats = kOffRowK + NY * kRowKWords;
 constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
 
@@ -259,40 +268,58 @@ struct BulkTasks { TaskAddr t[3]; };
 // worst the other way round.
 // bulk slot s = 0..5 of the schedules below: slots 0, 1 -> waves 0, 1; slots 2, 3 (the SIMDs that also carry a
 // polar wave) -> waves 6, 7; slots 4, 5 -> waves 4, 5.
-__host__ __device__ constexpr int bulk_slot(int wave) { return wave >= 6 ? wave - 4 : wave; }
-
 // The schedule (both arithmetic modes).  Task kinds: one row (S1 sub-cycled family, F1 full family) or two stacked rows (ST, FT).
-//   ST  rows (1,2) (3,4) (5,6) (7,8) (39,40) .. (45,46) : 8 pairs x 24 quads = 3 full passes
-//   FT  rows (10,11) .. (24,25)                          : 8 pairs x 24 quads = 3 full passes
-//   S1  rows 9, 38                                       : 48 tasks, one pass
-//   F1  rows 26 .. 37                                    : 288 tasks, 4.5 passes
-// Cost in instructions ~ ST 500, FT 380, S1 264, F1 199; waves w and w+4 share a SIMD and SIMDs 2, 3 also carry
-// a polar wave (~800), so:   w0: ST0 FT0   w4: ST1        (SIMD 0: 1380)
-//                            w1: ST2 F1_0  w5: S1 F1_1 F1_2 (SIMD 1: 1361)
-//                            w2: FT1 F1_3 (+ pole)          (SIMD 2: 579 + 800)
-//                            w3: FT2 F1_4 (+ pole)          (SIMD 3: 579 + 800)
+//   ST  rows (1,2) (3,4) (5,6) (7,8) (39,40) .. (45,46) : 8 pairs x 24 quads = 3 full passes   (~462 VALU instructions)
+//   FT  rows (10,11) .. (24,25)                          : 8 pairs x 24 quads = 3 full passes   (~270)
+//   S1  rows 9, 38                                       : 48 tasks, one pass                   (~298)
+//   F1  rows 26 .. 37                                    : 288 tasks, 4.5 passes                (~120)
+// Waves w and w+4 share a SIMD; waves 2 and 3 are the polar waves (a dependent chain of 8 Jacobi sweeps, ~5 300
+// cycles however little else runs).  In-kernel stamps (tools/stamp_member.py) give each wave's busy time per
+// sub-step: the older wave of a SIMD issues at ~7.5 cycles per instruction (its own LDS waits), the younger one in
+// the slots that leaves, and once the older wave is done the younger runs alone at that same 7.5 -- so the older
+// wave of a pair carries the larger share and the two should finish together.
 enum { kNone = 0, kS1 = 1, kF1 = 2, kST = 3, kFT = 4 };
-__host__ __device__ constexpr int fast_kind(int wave, int i) {
-  switch (wave) {
-    case 0: return i == 0 ? kST : (i == 1 ? kFT : kNone);
-    case 4: return i == 0 ? kST : kNone;
-    case 1: return i == 0 ? kST : (i == 1 ? kF1 : kNone);
-    case 5: return i == 0 ? kS1 : kF1;
-    case 2: case 3: return i == 0 ? kFT : (i == 1 ? kF1 : kNone);
-  }
-  return kNone;
+struct Pass { int kind, index; };
+#ifndef GREB_DEAL
+#define GREB_DEAL 0
+#endif
+__host__ __device__ constexpr Pass deal(int wave, int i) {
+  constexpr Pass none{kNone, 0};
+#if GREB_DEAL == 0
+  constexpr Pass t[8][3] = {
+      /* w0 */ {{kST, 0}, {kFT, 0}, none},     /* w1 */ {{kST, 2}, {kF1, 0}, none},
+      /* w2 */ {none, none, none},             /* w3 */ {none, none, none},
+      /* w4 */ {{kST, 1}, none, none},         /* w5 */ {{kS1, 0}, {kF1, 1}, {kF1, 2}},
+      /* w6 */ {{kFT, 1}, {kF1, 3}, none},     /* w7 */ {{kFT, 2}, {kF1, 4}, none}};
+#elif GREB_DEAL == 1
+  constexpr Pass t[8][3] = {
+      {{kST, 0}, {kFT, 0}, none},              {{kST, 2}, {kF1, 0}, {kF1, 1}},
+      {none, none, none},                      {none, none, none},
+      {{kST, 1}, none, none},                  {{kS1, 0}, {kF1, 2}, none},
+      {{kFT, 1}, {kF1, 3}, none},              {{kFT, 2}, {kF1, 4}, none}};
+#elif GREB_DEAL == 2
+  constexpr Pass t[8][3] = {
+      {{kST, 0}, {kF1, 0}, none},              {{kST, 2}, {kFT, 0}, none},
+      {none, none, none},                      {none, none, none},
+      {{kST, 1}, none, none},                  {{kS1, 0}, {kF1, 1}, none},
+      {{kFT, 1}, {kF1, 2}, {kF1, 3}},          {{kFT, 2}, {kF1, 4}, none}};
+#elif GREB_DEAL == 3
+  constexpr Pass t[8][3] = {
+      {{kST, 0}, {kFT, 0}, none},              {{kST, 1}, {kF1, 1}, {kF1, 2}},
+      {none, none, none},                      {none, none, none},
+      {{kS1, 0}, {kF1, 0}, none},              {{kST, 2}, none, none},
+      {{kFT, 1}, {kF1, 3}, none},              {{kFT, 2}, {kF1, 4}, none}};
+#elif GREB_DEAL == 4
+  constexpr Pass t[8][3] = {
+      {{kST, 0}, {kF1, 0}, {kF1, 1}},          {{kST, 2}, {kFT, 0}, none},
+      {none, none, none},                      {none, none, none},
+      {{kST, 1}, none, none},                  {{kS1, 0}, {kF1, 2}, none},
+      {{kFT, 1}, {kF1, 3}, none},              {{kFT, 2}, {kF1, 4}, none}};
+#endif
+  return t[wave][i];
 }
-__host__ __device__ constexpr int fast_index(int wave, int i) { // which pass of its kind
-  switch (wave) {
-    case 0: return 0;                    // ST0, FT0
-    case 4: return 1;                    // ST1
-    case 1: return i == 0 ? 2 : 0;       // ST2, F1_0
-    case 5: return i;                    // S1 (0), F1_1, F1_2
-    case 2: return i == 0 ? 1 : 3;       // FT1, F1_3
-    case 3: return i == 0 ? 2 : 4;       // FT2, F1_4
-  }
-  return 0;
-}
+__host__ __device__ constexpr int fast_kind(int wave, int i) { return deal(wave, i).kind; }
+__host__ __device__ constexpr int fast_index(int wave, int i) { return deal(wave, i).index; } // which pass of its kind
 
 // number of tasks of a pass: 64 = every lane has one
 __host__ __device__ constexpr int pass_tasks(int kind, int index) {
@@ -313,10 +340,11 @@ __device__ __forceinline__ BulkTasks make_tasks(int wave, int lane) {
       const int kind = fast_kind(wave, i), t = fast_index(wave, i) * 64 + lane;
       const int r = t / NQ;
       q = t % NQ;
-      if (kind == kST) { valid = r < 8; k = r < 4 ? 1 + 2 * r : 39 + 2 * (r - 4); }
+      // row order: consecutive r of a pass sit two rows (= 8 slot classes) apart wherever the rows allow it
+      if (kind == kST) { valid = r < 8; k = r < 4 ? 1 + 2 * r : (r == 4 ? 41 : (r == 5 ? 39 : (r == 6 ? 45 : 43))); }
       else if (kind == kFT) { valid = r < 8; k = 10 + 2 * r; }
-      else if (kind == kS1) { valid = r < 2; k = r == 0 ? 9 : 38; }
-      else if (kind == kF1) { valid = r < 12; k = 26 + r; }
+      else if (kind == kS1) { valid = r < 2; k = r == 0 ? 9 : 38; if (r == 1) q = (q + 4) % NQ; }
+      else if (kind == kF1) { valid = r < 12; k = r < 6 ? 26 + 2 * r : 27 + 2 * (r - 6); }
       if (!valid) { k = 1; q = 0; }
     }
     TaskAddr a;
@@ -330,7 +358,7 @@ __device__ __forceinline__ BulkTasks make_tasks(int wave, int lane) {
   return b;
 }
 
-// task i of bulk slot SLOT: kind and pass are compile-time, so a wave's sub-step is straight-line code -- no
+// task i of bulk wave SLOT: kind and pass are compile-time, so a wave's sub-step is straight-line code -- no
 // per-sub-step dispatch on the wave number (that dispatch, a switch on a VGPR lowered to exec-mask bookkeeping, cost
 // every bulk wave ~100 issue slots per sub-step)
 template <bool STRICT, int SLOT, int I>
@@ -372,15 +400,14 @@ __device__ __forceinline__ void st_pair2(lfloat* p, v2 a, v2 b) {
 }
 
 template <bool STRICT>
-__device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, bool calm_q = false) {
-  const int l = threadIdx.x & 63;
+__device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, int l /* lane */, bool calm_q = false) {
   if (l >= 48) return; // idle lanes (no workgroup barrier inside this function)
   const int k = pole ? NY - 1 : 0;
   const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
   const lfloat* Xc = lds + kOffX + cur * XB;
   const lfloat* Wc = lds + kOffW;
-  lfloat* bufA = lds + kOffScr + pole * 2 * RS;
-  lfloat* bufB = bufA + RS;
+  lfloat* bufA = lds + pole_buf(pole, 0);
+  lfloat* bufB = lds + pole_buf(pole, 1);
   v2 T0w[10], w[10];
   load_win10(Xc + k * RS, l, T0w);
   load_win10(Wc + k * RS, l, w);
@@ -530,10 +557,8 @@ __device__ __forceinline__ void stage_winds(lfloat* lds, const float* __restrict
 // the circulation loop shared by the member kernel and its test mirror
 template <bool STRICT>
 struct Circ {
-  BulkTasks tasks;
   __device__ __forceinline__ void init(lfloat* lds, const float* wz_air, const float* wz_vapor,
                                        const RowTables* __restrict__ tab) {
-    tasks = make_tasks<STRICT>(bulk_slot(threadIdx.x >> 6), threadIdx.x & 63);
     // guard rows of X[0], X[1], W: zero, never written again
     for (int i = threadIdx.x; i < 6 * RS; i += kThreads) {
       const int g = i / RS, o = i % RS; // buffer g >> 1, lower / upper guard g & 1
@@ -548,18 +573,22 @@ struct Circ {
   // number of barriers, each in its own loop).  WAVE is compile-time: the loop body is the wave's own straight-line
   // task sequence.  dbg: timing experiments only (tools/microbench_circ.py): bit0/1/2 skip sub / full / chain work.
   template <int WAVE>
-  __device__ __forceinline__ void role_loop(lfloat* lds, int cur, int nsub, int dbg, bool calm_q
+  __device__ __forceinline__ void role_loop(lfloat* lds, int cur, int nsub, int lane, int dbg, bool calm_q
 #ifdef GREB_TUNING
                                             , bool stamp, unsigned long long& busy
 #endif
   ) {
+    // the lane's task addresses: derived once per circulation call (not per launch -- values that live across the
+    // point-physics phase, where the register pressure peaks, come back as scratch reloads inside this loop)
+    BulkTasks tasks;
+    if constexpr (WAVE != 2 && WAVE != 3) tasks = make_tasks<STRICT>(WAVE, lane);
 #pragma unroll 1
     for (int tt = 0; tt < nsub; ++tt) {
 #ifdef GREB_TUNING
       const unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 #endif
-      if constexpr (WAVE == 2 || WAVE == 3) { if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, WAVE - 2, calm_q); }
-      else bulk_substep<STRICT, bulk_slot(WAVE)>(lds, cur, tasks, dbg, calm_q);
+      if constexpr (WAVE == 2 || WAVE == 3) { if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, WAVE - 2, lane, calm_q); }
+      else bulk_substep<STRICT, WAVE>(lds, cur, tasks, dbg, calm_q);
 #ifdef GREB_TUNING
       if (stamp) busy += __builtin_amdgcn_s_memtime() - t0;
 #endif
@@ -573,11 +602,13 @@ struct Circ {
                                            , bool stamp = false, unsigned long long* busy = nullptr
 #endif
   ) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane)); // opaque: nothing derived from it is hoisted out of the model-step loop
 #ifdef GREB_TUNING
     unsigned long long b = 0;
-#define GREB_ROLE(W) case W: role_loop<W>(lds, cur, nsub, dbg, calm_q, stamp, b); break;
+#define GREB_ROLE(W) case W: role_loop<W>(lds, cur, nsub, lane, dbg, calm_q, stamp, b); break;
 #else
-#define GREB_ROLE(W) case W: role_loop<W>(lds, cur, nsub, dbg, calm_q); break;
+#define GREB_ROLE(W) case W: role_loop<W>(lds, cur, nsub, lane, dbg, calm_q); break;
 #endif
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) { // a scalar branch per circulation call
       GREB_ROLE(0) GREB_ROLE(1) GREB_ROLE(2) GREB_ROLE(3) GREB_ROLE(4) GREB_ROLE(5) GREB_ROLE(6) GREB_ROLE(7)

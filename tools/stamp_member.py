@@ -17,6 +17,8 @@ import torch
 from greb_climate_model_amd import engine, ensemble, workload
 
 engine.use_tuning_build()
+if os.environ.get("GREB_LIB"):  # a variant build of the tuning library (deal experiments)
+    engine._lib_path = os.path.abspath(os.environ["GREB_LIB"])
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 years = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 inp = workload.make_inputs()
@@ -49,8 +51,7 @@ print(f"per model step (wave 0): wind staging {w0(wind):.0f} cyc, circulation {w
       f"physics+accumulation {w0(phys):.0f} cyc; total {np.median(cyc[:, 0]) / ns:.0f} cyc = {np.median(cyc[:, 0]) / ns / clk:.2f} us")
 sub = np.median(circ[:, 0]) / ns / nsb
 print(f"sub-step = {sub:.0f} cycles = {sub / clk:.3f} us; per wave busy cycles per sub-step and barrier wait share:")
-roles = {0: "bulk ST0 FT0", 1: "bulk ST2 F1_0", 2: "pole south", 3: "pole north", 4: "bulk ST1", 5: "bulk S1 F1_1 F1_2",
-         6: "bulk FT1 F1_3", 7: "bulk FT2 F1_4"}
 for w in range(8):
     b = np.median(busy[:, w]) / ns / nsb
-    print(f"  wave {w} (SIMD {w % 4}, {roles[w]:18s}): busy {b:6.0f} cyc  waits {100 * (1 - b / sub):4.1f} %")
+    print(f"  wave {w} (SIMD {w % 4}, {'pole' if w in (2, 3) else 'bulk'}): busy {b:6.0f} cyc  waits {100 * (1 - b / sub):4.1f} %")
+print(f"member-years/s at this launch time: {M / (np.median(rt[:, 0]) / 1e8) / max(1, -(-M // 256)):.0f}")
