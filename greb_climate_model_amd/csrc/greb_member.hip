@@ -119,14 +119,15 @@ __device__ __forceinline__ q8 fast_row(const q8& LT, const q8& CT, const q8& RT,
     w[j] = LW.v[j]; w[4 + j] = CW.v[j]; w[8 + j] = RW.v[j];
   }
   // the latitudinal advection term is not divided by 3 at k = 1 (v>=0 part) and k = ny-2 (v<0 part)
-  const float fm = k == 1 ? 3.f : 1.f, fp = k == NY - 2 ? 3.f : 1.f; // :766-769, :784-787
+  // (only rows 1 and NY-2, which are in the sub-cycled family: the full family skips the two multiplications)
+  const float fm = SUB && k == 1 ? 3.f : 1.f, fp = SUB && k == NY - 2 ? 3.f : 1.f; // :766-769, :784-787
   float um[4], up[4], vm[4], vp[4]; // the sign split is shared by the two tracers
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     split_sign(xq.v[i], um[i], up[i]);
     float a, b;
     split_sign(yq.v[i], a, b);
-    vm[i] = fm * a; vp[i] = fp * b;
+    vm[i] = SUB ? fm * a : a; vp[i] = SUB ? fp * b : b;
   }
   return substep_pair<SUB>(T, w, Tm2, Tm1, Tp1, Tp2, Wm2, Wm1, Wp1, Wp2, um, up, vm, vp, dif_cc * 0.05f, dif_ccy, last_quad,
                            calm_q);
@@ -260,62 +261,36 @@ __device__ __forceinline__ void row_task2(lfloat* lds, int cur, const TaskAddr& 
 
 struct BulkTasks { TaskAddr t[3]; };
 
-// Wave roles.  Waves w and w+4 share a SIMD, and the SIMD's issue arbiter favours the OLDER wave: the younger one
-// runs in the slots the older leaves.  So the heavy job of every SIMD sits on its older wave -- the heavy bulk
-// slots on waves 0 and 1, the two polar chains (~800 instructions, a dependent chain of 8 sweeps) on waves 2 and
-// 3 -- and the light bulk slots on waves 4-7.  Measured over 28 random deals of the same passes with equal SIMD
-// sums: 3 045 to 3 424 yr/s, best when the older wave of a pair carries ~880 and the younger ~500 instructions,
-// worst the other way round.
-// bulk slot s = 0..5 of the schedules below: slots 0, 1 -> waves 0, 1; slots 2, 3 (the SIMDs that also carry a
-// polar wave) -> waves 6, 7; slots 4, 5 -> waves 4, 5.
 // The schedule (both arithmetic modes).  Task kinds: one row (S1 sub-cycled family, F1 full family) or two stacked rows (ST, FT).
-//   ST  rows (1,2) (3,4) (5,6) (7,8) (39,40) .. (45,46) : 8 pairs x 24 quads = 3 full passes   (~462 VALU instructions)
-//   FT  rows (10,11) .. (24,25)                          : 8 pairs x 24 quads = 3 full passes   (~270)
-//   S1  rows 9, 38                                       : 48 tasks, one pass                   (~298)
-//   F1  rows 26 .. 37                                    : 288 tasks, 4.5 passes                (~120)
-// Waves w and w+4 share a SIMD; waves 2 and 3 are the polar waves (a dependent chain of 8 Jacobi sweeps, ~5 300
-// cycles however little else runs).  In-kernel stamps (tools/stamp_member.py) give each wave's busy time per
-// sub-step: the older wave of a SIMD issues at ~7.5 cycles per instruction (its own LDS waits), the younger one in
-// the slots that leaves, and once the older wave is done the younger runs alone at that same 7.5 -- so the older
-// wave of a pair carries the larger share and the two should finish together.
+//   ST  rows (1,2) (3,4) (5,6) (7,8) (39,40) .. (45,46) : 8 pairs x 24 quads = 3 full passes   (426 VALU instructions)
+//   FT  rows (10,11) .. (24,25)                          : 8 pairs x 24 quads = 3 full passes   (306)
+//   S1  rows 9, 38                                       : 48 tasks, one pass                   (223)
+//   F1  rows 26 .. 37                                    : 288 tasks, 4.5 passes                (156)
+// Waves w and w+4 share a SIMD; waves 2 and 3 are the polar waves (a dependent chain of 8 Jacobi sweeps, ~4 800
+// cycles however little else runs).  The SIMD's issue arbiter favours the OLDER wave; the younger one runs in the
+// slots that leaves, and once the older wave is done the younger runs alone at a single wave's issue rate (one
+// instruction per ~5 cycles at best, ~6-7 with its LDS waits) -- so the older wave of a pair carries the larger
+// share and the two should finish together.  In-kernel stamps (tools/stamp_member.py) give each wave's busy time
+// per sub-step.  The loop is VALU-pipe bound: a packed fp32 instruction occupies the SIMD for ~4.9 cycles (measured,
+// tools/ubench/valu_rate.hip; a scalar one ~2.3-2.7), which puts the work dealt to SIMD 0 at ~5 160 pipe cycles of
+// the 5 620 it takes.
 enum { kNone = 0, kS1 = 1, kF1 = 2, kST = 3, kFT = 4 };
 struct Pass { int kind, index; };
-#ifndef GREB_DEAL
-#define GREB_DEAL 0
-#endif
 __host__ __device__ constexpr Pass deal(int wave, int i) {
   constexpr Pass none{kNone, 0};
-#if GREB_DEAL == 0
+  // Measured sub-step times of the deals tried (in-kernel stamps, 512 members, cycles at 2.36 GHz; the first line is
+  // round 1's deal):   w0 ST0 FT0 | w4 ST1 ; w1 ST2 F1_0 | w5 S1 F1_1 F1_2 ; w6 FT1 F1_3 ; w7 FT2 F1_4   6 299
+  //                    the table below (one F1 pass moved from the younger to the older wave of SIMD 1)        5 838
+  //                    ... and the other F1 pass of wave 5 moved to wave 6 (pole SIMD)                         6 115
+  //                    w0 ST0 F1 F1 | w4 ST1 ; w1 ST2 FT0 | w5 S1 F1 ; w6 FT1 F1 ; w7 FT2 F1                   6 059
+  //                    an ST pass on a pole SIMD (w6 ST2), FT1 F1 on w4                                        6 210
+  // Static s_setprio 1 on the younger waves, on waves 6/7 or on the polar waves: 6 847 / 6 661 / 5 855 -- the
+  // prioritised wave runs its instructions at ~6 cycles each and its partner then runs alone; age order is best.
   constexpr Pass t[8][3] = {
-      /* w0 */ {{kST, 0}, {kFT, 0}, none},     /* w1 */ {{kST, 2}, {kF1, 0}, none},
+      /* w0 */ {{kST, 0}, {kFT, 0}, none},     /* w1 */ {{kST, 2}, {kF1, 0}, {kF1, 1}},
       /* w2 */ {none, none, none},             /* w3 */ {none, none, none},
-      /* w4 */ {{kST, 1}, none, none},         /* w5 */ {{kS1, 0}, {kF1, 1}, {kF1, 2}},
+      /* w4 */ {{kST, 1}, none, none},         /* w5 */ {{kS1, 0}, {kF1, 2}, none},
       /* w6 */ {{kFT, 1}, {kF1, 3}, none},     /* w7 */ {{kFT, 2}, {kF1, 4}, none}};
-#elif GREB_DEAL == 1
-  constexpr Pass t[8][3] = {
-      {{kST, 0}, {kFT, 0}, none},              {{kST, 2}, {kF1, 0}, {kF1, 1}},
-      {none, none, none},                      {none, none, none},
-      {{kST, 1}, none, none},                  {{kS1, 0}, {kF1, 2}, none},
-      {{kFT, 1}, {kF1, 3}, none},              {{kFT, 2}, {kF1, 4}, none}};
-#elif GREB_DEAL == 2
-  constexpr Pass t[8][3] = {
-      {{kST, 0}, {kF1, 0}, none},              {{kST, 2}, {kFT, 0}, none},
-      {none, none, none},                      {none, none, none},
-      {{kST, 1}, none, none},                  {{kS1, 0}, {kF1, 1}, none},
-      {{kFT, 1}, {kF1, 2}, {kF1, 3}},          {{kFT, 2}, {kF1, 4}, none}};
-#elif GREB_DEAL == 3
-  constexpr Pass t[8][3] = {
-      {{kST, 0}, {kFT, 0}, none},              {{kST, 1}, {kF1, 1}, {kF1, 2}},
-      {none, none, none},                      {none, none, none},
-      {{kS1, 0}, {kF1, 0}, none},              {{kST, 2}, none, none},
-      {{kFT, 1}, {kF1, 3}, none},              {{kFT, 2}, {kF1, 4}, none}};
-#elif GREB_DEAL == 4
-  constexpr Pass t[8][3] = {
-      {{kST, 0}, {kF1, 0}, {kF1, 1}},          {{kST, 2}, {kFT, 0}, none},
-      {none, none, none},                      {none, none, none},
-      {{kST, 1}, none, none},                  {{kS1, 0}, {kF1, 2}, none},
-      {{kFT, 1}, {kF1, 3}, none},              {{kFT, 2}, {kF1, 4}, none}};
-#endif
   return t[wave][i];
 }
 __host__ __device__ constexpr int fast_kind(int wave, int i) { return deal(wave, i).kind; }
@@ -479,10 +454,18 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, in
             const v2 a = Pp[c] - Pm[c - 1], b = Pp[c + 1] - Pm[c - 2], g = Pp[c + 2] - Pm[c - 3];
             d[pt] = cs * (6.f * a + (3.f * b + g));
           }
-          v2 dd = d[pt];
-          dd.x = (dd.x <= -T[c].x) ? -0.9f * T[c].x : dd.x;
-          dd.y = (dd.y <= -T[c].y) ? -0.9f * T[c].y : dd.y;
-          th[pt] = T[c] + dd;
+          th[pt] = T[c] + d[pt];
+        }
+        // the clamp (:715 / :907) as in substep_pair: one min decides whether any component needs the select
+        if (__builtin_expect(!(min3f(min3f(th[0].x, th[0].y, th[1].x), th[1].y, th[1].y) > 0.f), 0)) {
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            const int c = 4 + pt;
+            v2 dd = d[pt];
+            dd.x = (dd.x <= -T[c].x) ? -0.9f * T[c].x : dd.x;
+            dd.y = (dd.y <= -T[c].y) ? -0.9f * T[c].y : dd.y;
+            th[pt] = T[c] + dd;
+          }
         }
       }
       if (tt + 1 < time2) { // publish for the neighbours' next sweep

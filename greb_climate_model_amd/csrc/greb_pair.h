@@ -57,6 +57,13 @@ __device__ __forceinline__ void split_sign(float u, float& pos, float& neg) {
   neg = u - pos;
 }
 
+// min of three finite-or-NaN values as ONE v_min3_f32 (fminf would add a canonicalising v_max per operand)
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 struct Flux2 {
   v2 Pp[10]; // Pp[m] = w[m+1]*(T[m+1]-T[m]), m = 4..9
   v2 Pm[10]; // Pm[m] = w[m]  *(T[m+1]-T[m]), m = 1..6
@@ -147,11 +154,24 @@ __device__ __forceinline__ q8 substep_pair(const v2 T[12], const v2 w[12], const
   v2 ddx[4], dax[4], ddy[4], day[4];
   dif_lon2(f, cs_dif, ddx);
   if (SUB) {
-    v2 T1h[4] = {T[4], T[5], T[6], T[7]};
-    v2 T2h[4] = {T[4], T[5], T[6], T[7]};
-    clamp_add2(T1h, ddx);
     adv_lon_sub2(f, T, w, um, up, last_quad, dax);
-    clamp_add2(T2h, dax);
+    // The sub-cycle clamp `where(dTxh <= -T1h) dTxh = -0.9*T1h` (:715, :907) fires only where an increment would take
+    // the tracer to zero or below.  d <= -T implies fl(T + d) <= 0 (rounding is monotonic), so one min over the 16
+    // updated values (v_min3 chain) decides conservatively whether any lane component needs the reference's
+    // per-component select; the common path is 9 instructions instead of 16 compares + 16 selects per row.
+    v2 T1h[4], T2h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { T1h[i] = T[4 + i] + ddx[i]; T2h[i] = T[4 + i] + dax[i]; }
+    float mn = min3f(T1h[0].x, T1h[0].y, T1h[1].x);
+    mn = min3f(mn, T1h[1].y, T1h[2].x); mn = min3f(mn, T1h[2].y, T1h[3].x); mn = min3f(mn, T1h[3].y, T2h[0].x);
+    mn = min3f(mn, T2h[0].y, T2h[1].x); mn = min3f(mn, T2h[1].y, T2h[2].x); mn = min3f(mn, T2h[2].y, T2h[3].x);
+    mn = min3f(mn, T2h[3].y, T2h[3].y);
+    if (__builtin_expect(!(mn > 0.f), 0)) { // also taken for a NaN: the reference's own comparisons then decide
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { T1h[i] = T[4 + i]; T2h[i] = T[4 + i]; }
+      clamp_add2(T1h, ddx);
+      clamp_add2(T2h, dax);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ddx[i] = T1h[i] - T[4 + i]; dax[i] = T2h[i] - T[4 + i]; } // :718, :910
   } else {
