@@ -27,6 +27,13 @@ def inputs():
 
 
 @pytest.fixture(scope="session")
+def inputs384():
+    """The workload bilinearly refined to 384x192 (BASELINE configs 3 and 5): 1.5 GB, built once."""
+    from greb_climate_model_amd import workload
+    return workload.make_inputs(384, 192)
+
+
+@pytest.fixture(scope="session")
 def params():
     """Reference defaults + the shipped namelist's diagnostic point (namelist:4-5)."""
     from greb_climate_model_amd import abi

@@ -232,31 +232,97 @@ def test_multilaunch_engine_g96_vs_reference(eng_mod, params, inputs, strict):
     e.close()
 
 
-def test_engine_g384_vs_oracle(eng_mod, oracle_lib):
-    """BASELINE config 3's grid: 384x192 (bilinear-upsampled inputs), 1 flux-correction year + 1
-    scenario year, 2 members (CO2 340 / 680) against the oracle at the same grid, in STRICT arithmetic (scalar
-    any-grid kernel) and in FAST arithmetic (the (Tair,q)-pair kernel of greb_pair_sweep.hip).  Every row
-    is sub-cycled (up to 225 sweeps); the two polar rows keep the reference's inherited
-    time2 = 1, ccx2 = 0 behaviour."""
+def _g384_reductions_close(mon, g, label, months=None):
+    """All months of a 384x192 run against the reference's per-month reductions (the full output is 35 MB and not
+    committed): zonal means per latitude row and eight polar rows in full -- the rows where the reference's
+    sub-cycling semantics differ most from 96x48 (225-sweep chains, the NINT(Inf) rows)."""
+    n = mon.shape[0] if months is None else months
+    zon = mon[:n].astype(np.float64).mean(axis=3)
+    for i, (name, tol) in enumerate(TOL.items()):
+        dz = np.abs(zon[:, i] - g["zonal"][:n, i]).max()
+        r = rms(mon[:n, i][:, list(g["rows"])], g["polar_rows"][:n, i])
+        print(f"{label:>24s} {name:7s} zonal-mean max diff {dz:.2e}  polar-rows rms {r:.2e} (tol {tol:.0e})")
+        assert dz < 2 * tol and r < 2 * tol, (label, name, dz, r)
+
+
+@pytest.mark.parametrize("kappa", [None, 7.2e5])
+def test_strict_stencils_bit_exact_g384_vs_reference(eng_mod, oracle_lib, inputs384, kappa):
+    """384x192 stencils against the REFERENCE's own diffusion / advection / circulation compiled at that grid
+    (tests/golden/routine_g384.npz, oracle/Makefile ref384): STRICT bit-exact, FAST within the re-association
+    tolerance; kappa = 7.2e5 puts 1 800 dependent sweeps into each polar row."""
     from greb_climate_model_amd import abi, workload
-    inp = workload.make_inputs(384, 192)
-    p = abi.default_params(ipx=380, ipy=150)
-    o = oracle_lib.Oracle(inp, p)
-    yfo = o.flux_correction(1)
-    ref, yro = o.run(1, 680.0)
+    g = load_golden("routine_g384.npz")
+    p = abi.default_params()
+    tag = ""
+    if kappa is not None:
+        p.kappa, tag = kappa, "_k72"
+    Ta, q, ityr = workload.routine_inputs_g384(inputs384)
+    o = oracle_lib.Oracle(inputs384, p)  # only for the weights wz_air / wz_vapor (src/greb.f90:201-202)
+    wa, wv = o.field(5).copy(), o.field(6).copy()
     o.close()
-    # 2 members: scalar kernel; 40 members (the engine's threshold for the pair kernel): member 39 carries 680 ppm
-    for strict, nm in ((True, 2), (False, 2), (False, 40)):
-        e = eng_mod.Engine(inp, p, n_members=nm, strict=strict)
-        yf = e.flux_correction(1)
-        co2 = np.full((nm, 1), 340.0, np.float32); co2[-1] = 680.0
-        mon, yr = e.run(1, co2)
-        e.close()
-        _check_run(mon[-1, 0], ref[0], f"g384 strict={strict} members={nm}")
-        yearly_close(yf[-1], yfo, strict, 384 * 192); yearly_close(yr[-1], yro, strict, 384 * 192)
-        assert rms(mon[0, 0, 11, 0], mon[-1, 0, 11, 0]) > 1e-2  # the members differ (CO2)
-        if nm > 2:
-            assert np.array_equal(mon[0], mon[1])  # replicas agree bit for bit
+    u, v = inputs384.uclim[ityr - 1], inputs384.vclim[ityr - 1]
+    X = np.stack([Ta, q]); W = np.stack([wa, wv]); U = np.stack([u, u]); V = np.stack([v, v])
+    d = eng_mod.diffusion(X, W, p, strict=True)
+    assert np.array_equal(d[0], g["dif_Ta" + tag])
+    c = eng_mod.circulation(X, W, U, V, p, strict=True)
+    assert np.array_equal(c[0], g["crc_Ta" + tag])
+    if kappa is None:
+        a = eng_mod.advection(X, W, U, V, p, strict=True)
+        assert np.array_equal(d[1], g["dif_q"]) and np.array_equal(a[0], g["adv_Ta"]) and np.array_equal(a[1], g["adv_q"])
+        assert np.array_equal(c[1], g["crc_q"])
+    for name, got, ref in (("dif", eng_mod.diffusion(X, W, p)[0], g["dif_Ta" + tag]),
+                           ("crc", eng_mod.circulation(X, W, U, V, p)[0], g["crc_Ta" + tag])):
+        scale = np.abs(ref).max()
+        assert np.abs(got.astype(np.float64) - ref).max() < (2e-6 if name == "dif" else 2e-5) * scale, name
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast", "pairs"])
+def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
+    """BASELINE config 3 in miniature against the REFERENCE compiled at 384x192 (g384_short.npz): 1+2 yr, 2xCO2.
+    strict / fast: 2 members on the scalar any-grid kernel; pairs: 40 members, the engine's threshold for the
+    (Tair,q)-pair kernel of greb_pair_sweep.hip.  Months 1, 12, 24 in full, every month by zonal means and polar rows."""
+    from greb_climate_model_amd import abi
+    g = load_golden("g384_short.npz")
+    p = abi.default_params(ipx=380, ipy=152)
+    nm = 40 if mode == "pairs" else 2
+    e = eng_mod.Engine(inputs384, p, n_members=nm, strict=mode == "strict")
+    yf = e.flux_correction(1)
+    co2 = np.full((nm, 2), 340.0, np.float32); co2[-1] = 680.0
+    mon, yr = e.run(2, co2)
+    e.close()
+    last = mon[-1].reshape(24, 5, 192, 384)
+    _check_run(last[[0, 11, 23]], g["monthly_sel"], f"g384 {mode}")
+    _g384_reductions_close(last, g, f"g384 {mode}")
+    yearly_close(np.concatenate([yf[-1], yr[-1]]), g["yearly"], mode == "strict", 384 * 192)
+    assert rms(mon[0, 1, 11, 0], mon[-1, 1, 11, 0]) > 1e-2  # the members differ (CO2)
+    if nm > 2:
+        assert np.array_equal(mon[0], mon[1])  # replicas agree bit for bit
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast", "pairs"])
+def test_config5_perturbed_members_g384_vs_reference(eng_mod, inputs384, mode):
+    """BASELINE config 5 in miniature: perturbed-physics members at 384x192 -- per-member RowTables (own kappa),
+    own flux corrections (shared_corr = false), the multi-launch engine and, in `pairs`, the pair kernel -- against
+    five separate runs of the reference with the same &PHYSICS_PAR (g384_physpar.npz), 1+1 yr.  Member 4 has
+    kappa = 7.2e5: 1 800 dependent sweeps in each polar row (inherited semantics, src/greb.f90:652-654)."""
+    from greb_climate_model_amd import abi
+    g = load_golden("g384_physpar.npz")
+    ov = g["overrides"]
+    reps = 8 if mode == "pairs" else 1  # 40 members: the pair kernel
+    overrides = [dict(zip(("da_ice", "a_no_ice", "a_cloud", "kappa"), map(float, ov[m % 5]))) for m in range(5 * reps)]
+    e = eng_mod.Engine(inputs384, abi.default_params(ipx=380, ipy=152), n_members=5 * reps, overrides=overrides,
+                       strict=mode == "strict")
+    yf = e.flux_correction(1)
+    mon, yr = e.run(1, 680.0)
+    e.close()
+    for m in range(5):
+        mm = mon[5 * (reps - 1) + m, 0]
+        _check_run(mm[11][None], g["december"][m][None], f"cfg5 {mode} m{m}")
+        _g384_reductions_close(mm, {k: g[k][m] if k != "rows" else g[k] for k in ("zonal", "polar_rows", "rows")}, f"cfg5 {mode} m{m}")
+        yearly_close(np.concatenate([yf[5 * (reps - 1) + m], yr[5 * (reps - 1) + m]]), g["yearly"][m], mode == "strict", 384 * 192)
+    assert rms(mon[0, 0, 11, 0], mon[1, 0, 11, 0]) > 1e-3  # different physics, different climate
+    if reps > 1:
+        assert np.array_equal(mon[0], mon[5])  # replicas agree bit for bit
 
 
 # ------------------------------------------------------------------------------------ error behaviour

@@ -140,3 +140,67 @@ def test_run_without_flux_correction_bit_exact(inputs, params, oracle_lib):
     o.close()
     mon = mon.reshape(12, 5, 48, 96)
     assert hashlib.sha256(np.ascontiguousarray(mon).tobytes()).digest() == g["sha256"].tobytes()
+
+
+# ------------------------------------------------------------------------------------ 384x192 (BASELINE configs 3, 5)
+def test_manifest_says_pinned_at_g384():
+    """tests/golden/make_golden_g384.py asserted the oracle bit-identical to the reference compiled with
+    xdim = 384, ydim = 192 (oracle/Makefile ref384): per routine, for a 1+2-yr run, and for five perturbed-physics
+    members (one with 1 800-sweep polar rows)."""
+    m = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    for k in ("routine_g384", "g384_short", "g384_physpar"):
+        assert m["items"][k]["oracle_bit_identical"] is True, k
+    assert m["items"]["g384_short"]["grid"] == [384, 192] and len(m["items"]["g384_short"]["month_sha256"]) == 24
+    assert m["items"]["g384_physpar"]["members"] == 5
+
+
+@pytest.mark.parametrize("kappa", [None, 7.2e5])
+def test_routines_bit_exact_g384(inputs384, oracle_lib, kappa):
+    """One call each of diffusion / advection / circulation at 384x192 against the reference's own subroutines
+    (routine_g384.npz): every row sub-cycled, up to 225 dependent sweeps, and the polar rows where the reference's
+    integer dtdff2 is 0 (one sweep, ccx2 = 0; src/greb.f90:652-654) -- or 1, i.e. 1 800 sweeps, at kappa = 7.2e5."""
+    from greb_climate_model_amd import abi, workload
+    g = load_golden("routine_g384.npz")
+    gs = load_golden("g384_short.npz")
+    p = abi.default_params()
+    if kappa is not None:
+        p.kappa = kappa
+    o = oracle_lib.Oracle(inputs384, p)
+    grid = o.grid()
+    tag = "" if kappa is None else "_k72"
+    if kappa is None:
+        for k in ("dif_time2", "adv_time2", "dif_ccx2", "adv_ccx2", "subcycled"):
+            assert np.array_equal(np.asarray(grid[k]), gs["grid_" + k]), k
+        assert int(grid["dif_time2"][0]) == 1 and float(grid["dif_ccx2"][0]) == 0.0       # NINT(Inf) rows
+        assert int(grid["dif_time2"][1]) == 225 and int(grid["subcycled"].sum()) == 192   # SURVEY.md App. B
+    else:
+        assert int(grid["dif_time2"][0]) == 1800 and int(grid["dif_time2"][191]) == 1800
+    Ta, q, ityr = workload.routine_inputs_g384(inputs384)
+    wa, wv = o.field(5).copy(), o.field(6).copy()
+    assert np.array_equal(o.diffusion(Ta, wa), g["dif_Ta" + tag])
+    assert np.array_equal(o.circulation(Ta, wa, ityr=ityr), g["crc_Ta" + tag])
+    if kappa is None:
+        assert np.array_equal(o.diffusion(q, wv), g["dif_q"])
+        assert np.array_equal(o.advection(Ta, wa, ityr=ityr), g["adv_Ta"])
+        assert np.array_equal(o.advection(q, wv, ityr=ityr), g["adv_q"])
+        assert np.array_equal(o.circulation(q, wv, ityr=ityr), g["crc_q"])
+    o.close()
+
+
+def test_run_g384_first_year_bit_exact(inputs384, oracle_lib):
+    """The oracle's 1+1-yr run at 384x192 against the reference binary's output: months 1 and 12 in full, all twelve
+    months by their sha256 (MANIFEST.json), zonal means and polar rows."""
+    import hashlib
+    from greb_climate_model_amd import abi
+    g = load_golden("g384_short.npz")
+    m = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))["items"]["g384_short"]
+    o = oracle_lib.Oracle(inputs384, abi.default_params(ipx=380, ipy=152))
+    yf = o.flux_correction(1)
+    mon, yr = o.run(1, 680.0)
+    o.close()
+    mon = mon.reshape(12, 5, 192, 384)
+    assert np.array_equal(mon[0], g["monthly_sel"][0]) and np.array_equal(mon[11], g["monthly_sel"][1])
+    for i in range(12):
+        assert hashlib.sha256(np.ascontiguousarray(mon[i]).tobytes()).hexdigest() == m["month_sha256"][i], i
+    assert np.array_equal(mon[:, :, list(g["rows"])], g["polar_rows"][:12])
+    assert np.allclose(np.concatenate([yf, yr]), g["yearly"][:2], rtol=0, atol=6e-4)
