@@ -221,12 +221,18 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         roof = roofline_diffusion(torch, engine, params, args.roofline_batch, args.strict)
-    cpu = cpu_all = delivered = None
+    cpu = cpu_all = delivered = g384 = None
     if rank == 0 and world == 1:
         delivered = host_delivered(torch, eng, levels, M, min(K, 4))
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(inp)
         cpu_all = cpu_baseline_all_cores(inp)
+
+    if rank == 0 and world == 1 and not args.no_g384:
+        eng.close()  # the 384x192 ensemble wants the HBM (41 GB of per-member flux corrections at 64 members)
+        del monthly, year_bufs
+        torch.cuda.empty_cache()
+        g384 = g384_object(torch, engine, ensemble, workload, local_rank, args.strict)
 
     if rank == 0:
         out = {
@@ -255,6 +261,8 @@ def main():
             out["roofline"] = roof
         if delivered is not None:
             out["host_delivered"] = delivered
+        if g384 is not None:
+            out["g384"] = g384
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if cpu_all is not None:
@@ -312,6 +320,75 @@ def roofline_diffusion(torch, engine, params, batch, strict, sweeps=20):
             "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(avg * 1e3, 4), "batch": batch,
             "min_launch_ms": round(float(np.min(ms)), 4), "measured_copy_GBps": round(copy_gbs, 1),
             "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
+
+
+def g384_object(torch, engine, ensemble, workload, device, strict):
+    """BASELINE configs 3 and 5 at their own grid, 384x192 (inputs: the synthetic workload bilinearly refined,
+    SURVEY.md C.1), one scenario year each after one flux-correction year:
+      config3   1 member (any-grid multi-launch engine: 24 band sub-step launches + 1 point-physics launch per model
+                step); bound by the latency of the longest Jacobi chain of a launch (row 2: 225 dependent sweeps)
+      config5   64 perturbed-physics members (da_ice, a_no_ice, a_cloud, kappa +-10 %, ensemble.perturbed_physics), as
+                drawn, and without the members whose kappa < 7.27e5 gives the two polar rows 1 800 dependent diffusion
+                sweeps per call instead of none (the reference's integer dtdff2 is 1 instead of 0 there,
+                src/greb.f90:652-654 -- inherited semantics, kept; those members set the length of every launch)
+      diffusion the standalone batched diffusion sweep at this grid against the same 12 B/point definition as the
+                96x48 roofline line (884 736 B per field, batch 1 024 = 0.9 GB per launch): every row is sub-cycled
+                here, so the kernel is bound by the chain rows' arithmetic, not by HBM"""
+    import gc
+    nx, ny = 384, 192
+    inp = workload.make_inputs(nx, ny)
+    p = engine.params_default(); p.ipx, p.ipy = 380, 152
+    out = {"grid": [nx, ny], "arithmetic": "strict" if strict else "fast"}
+
+    def year_rate(n_members, overrides):
+        e = engine.Engine(inp, p, n_members=n_members, overrides=overrides, device=device, strict=strict)
+        e.flux_correction(1)
+        buf = torch.empty((n_members, 1, 12, 5, e.np), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        e.run(1, 680.0, monthly_dev_ptr=buf.data_ptr())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        ok = bool(torch.isfinite(buf).all().item())
+        e.close(); del buf
+        gc.collect(); torch.cuda.empty_cache()
+        return n_members / dt, dt, ok
+
+    r, dt, ok = year_rate(1, None)
+    out["config3_single_member"] = {"years_per_s": round(r, 3), "us_per_substep_launch": round(dt / (730 * 25) * 1e6, 2),
+                                    "finite": ok, "bound": "latency of one wave's 225-sweep polar chain per launch"}
+    ov = ensemble.perturbed_physics(64, p)
+    as_dicts = lambda rows: [dict(zip(ensemble.PERTURBED, map(float, row))) for row in rows]
+    r, dt, ok = year_rate(64, as_dicts(ov))
+    slow = ov[:, 3] < 7.27e5
+    out["config5_64_members"] = {"member_years_per_s": round(r, 2), "finite": ok, "members_with_1800_sweep_polar_rows": int(slow.sum()),
+                                 "bound": "latency of the 1800-sweep polar chains of the kappa < 7.27e5 members"}
+    keep = ov[~slow]
+    r, dt, ok = year_rate(len(keep), as_dicts(keep))
+    out["config5_without_those_members"] = {"members": int(len(keep)), "member_years_per_s": round(r, 2), "finite": ok,
+                                            "bound": "VALU issue of the chain rows (pair kernel)"}
+    # standalone diffusion sweep, HIP events on the launching stream
+    batch = 1024
+    n = batch * nx * ny
+    g = torch.Generator(device="cuda").manual_seed(2)
+    T1 = 250.0 + 50.0 * torch.rand(n, device="cuda", generator=g)
+    wz = 0.3 + 0.7 * torch.rand(n, device="cuda", generator=g)
+    dX = torch.empty(n, device="cuda")
+    st = torch.cuda.current_stream()
+    engine.diffusion_dev(p, nx, ny, batch, T1.data_ptr(), wz.data_ptr(), dX.data_ptr(), strict, 2, st.cuda_stream)
+    torch.cuda.synchronize()
+    sweeps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    engine.diffusion_dev(p, nx, ny, batch, T1.data_ptr(), wz.data_ptr(), dX.data_ptr(), strict, sweeps, st.cuda_stream)
+    e1.record(st); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / sweeps
+    achieved = 12.0 * n / (ms * 1e-3) / 1e9
+    out["diffusion_sweep"] = {"kernel": "sweep_kernel<dif> (latitude bands)", "batch": batch, "algorithmic_bytes_per_launch": int(12 * n),
+                              "avg_launch_ms": round(ms, 4), "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                              "frac": round(achieved / 8000.0, 4),
+                              "bound": "VALU: 1 044 row-sweeps per field (SURVEY.md App. B) against 192 rows of traffic"}
+    return out
 
 
 def host_delivered(torch, eng, levels, M, years):

@@ -152,7 +152,7 @@ def main():
         # ------------------------------------------------------------ perturbed physics, 1+1 yr (config 5)
         # four drawn members + one with kappa = 7.2e5: below 7.27e5 the integer dtdff2 of the two polar rows is 1
         # instead of 0 (src/greb.f90:652-654), i.e. 1 800 dependent diffusion sweeps per call there instead of none --
-        # the members that dominate config 5's run time (18 of its 64 draws)
+        # the members that set the length of every launch in config 5 (2 of its 64 draws)
         ov = np.concatenate([perturbed_physics(4, abi.default_params()), np.asarray([[0.25, 0.1, 0.35, 7.2e5]], f32)])
         dec, zon, pol, sts, yrs, hashes, walls, all_eq = [], [], [], [], [], [], [], True
         for m in range(len(ov)):
