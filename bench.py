@@ -310,7 +310,7 @@ def roofline_diffusion(torch, engine, params, batch, strict, sweeps=20):
     # (gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md) + WRITE_SIZE, scaled to this batch
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_roofline_traffic.json")) as f:
             tj = json.load(f)
         traffic = int(tj["traffic_bytes_per_launch"] * batch / tj["batch"])
     except (OSError, KeyError, ValueError):

@@ -80,6 +80,13 @@ __device__ __forceinline__ void load_window(P row, int q, int nq, float t[12]) {
   for (int i = 0; i < 4; ++i) { t[i] = a.v[i]; t[4 + i] = b.v[i]; t[8 + i] = c.v[i]; }
 }
 
+// min of three finite-or-NaN values as ONE v_min3_f32 (fminf would add a canonicalising v_max per operand)
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 __device__ __forceinline__ float split_m(float u) { return u >= 0.0f ? u : 0.0f; } // src/greb.f90:203-205
 __device__ __forceinline__ float split_p(float u) { return u >= 0.0f ? 0.0f : u; } // src/greb.f90:206-208
 

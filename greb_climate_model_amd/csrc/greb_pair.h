@@ -57,13 +57,6 @@ __device__ __forceinline__ void split_sign(float u, float& pos, float& neg) {
   neg = u - pos;
 }
 
-// min of three finite-or-NaN values as ONE v_min3_f32 (fminf would add a canonicalising v_max per operand)
-__device__ __forceinline__ float min3f(float a, float b, float c) {
-  float r;
-  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
 struct Flux2 {
   v2 Pp[10]; // Pp[m] = w[m+1]*(T[m+1]-T[m]), m = 4..9
   v2 Pm[10]; // Pm[m] = w[m]  *(T[m+1]-T[m]), m = 1..6

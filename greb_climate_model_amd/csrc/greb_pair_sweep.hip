@@ -20,6 +20,7 @@ namespace greb {
 namespace {
 
 constexpr int kPairNx = 384, kPairNq = 96, kPairP = 6;
+static_assert(kPairP == 6, "the chain's min3 reduction is written for six points per lane");
 constexpr int kPHalf = 4 * kPairNq;  // floats per half-row
 constexpr int kPRow = 2 * kPHalf;    // floats per LDS row (768)
 
@@ -61,6 +62,24 @@ __device__ void pair_chain_row(const lfloat* sT, const lfloat* sW, const lfloat*
   v2 Th[2][P];
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
+    // The weights, the row constant and the (pre-scaled) wind do not change during the chain: the increment of
+    // point c is a fixed linear form in the six differences e[m] = T[m+1] - T[m] around it, per tracer -- the same
+    // coefficient form as the scalar any-grid kernel (greb_stencil.h: chain_lon_regs), on (Tair, q) pairs.
+    v2 K[P][6];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int c = 3 + i;
+      if (which) { // -neg*(10 Pp[c] + 4 Pp[c+1] + Pp[c+2]) - pos*(10 Pm[c-1] + 4 Pm[c-2] + Pm[c-3]), :845-851
+        float pos, neg;
+        split_sign(us[i], pos, neg);
+        K[i][0] = -pos * w[c - 3]; K[i][1] = (-4.f * pos) * w[c - 2]; K[i][2] = (-10.f * pos) * w[c - 1];
+        K[i][3] = (-10.f * neg) * w[c + 1]; K[i][4] = (-4.f * neg) * w[c + 2]; K[i][5] = -neg * w[c + 3];
+        if (i == P - 3 && bug_lane) { K[i][4] = -neg * w[c + 3]; K[i][5] = -neg * w[c + 3]; } // :881
+      } else { // cs*(6(Pp[c] - Pm[c-1]) + 3(Pp[c+1] - Pm[c-2]) + (Pp[c+2] - Pm[c-3])), :595-600
+        K[i][0] = -cs * w[c - 3]; K[i][1] = (-3.f * cs) * w[c - 2]; K[i][2] = (-6.f * cs) * w[c - 1];
+        K[i][3] = (6.f * cs) * w[c + 1]; K[i][4] = (3.f * cs) * w[c + 2]; K[i][5] = cs * w[c + 3];
+      }
+    }
     v2 T[W];
 #pragma unroll
     for (int i = 0; i < W; ++i) T[i] = T0[i];
@@ -72,34 +91,30 @@ __device__ void pair_chain_row(const lfloat* sT, const lfloat* sW, const lfloat*
           T[P + 3 + i] = dpp_next(T[3 + i]);
         }
       }
-      v2 Pp[W], Pm[W];
+      v2 e[W - 1];
 #pragma unroll
-      for (int m = 0; m < W - 1; ++m) {
-        const v2 e = pk_sub(T[m + 1], T[m]);
-        Pp[m] = w[m + 1] * e; Pm[m] = w[m] * e;
-      }
-      v2 Tn[P];
+      for (int m = 0; m < W - 1; ++m) e[m] = pk_sub(T[m + 1], T[m]);
+      v2 Tn[P], dv[P];
 #pragma unroll
       for (int i = 0; i < P; ++i) {
-        const int c = 3 + i;
-        v2 d;
-        if (which) {
-          float pos, neg;
-          split_sign(us[i], pos, neg);
-          const v2 am = 10.f * Pm[c - 1] + (4.f * Pm[c - 2] + Pm[c - 3]);
-          v2 ap = 10.f * Pp[c] + (4.f * Pp[c + 1] + Pp[c + 2]);
-          if (i == P - 3) {
-            const v2 bug = 10.f * Pp[c] - w[c + 3] * pk_sub(T[c + 1], T[c + 3]);
-            ap = bug_lane ? bug : ap;
-          }
-          d = -neg * ap - pos * am;
-        } else {
-          const v2 a = pk_sub(Pp[c], Pm[c - 1]), b = pk_sub(Pp[c + 1], Pm[c - 2]), g = pk_sub(Pp[c + 2], Pm[c - 3]);
-          d = cs * (6.f * a + (3.f * b + g));
+        v2 d = K[i][0] * e[i];
+#pragma unroll
+        for (int m = 1; m < 6; ++m) d = __builtin_elementwise_fma(K[i][m], e[i + m], d);
+        dv[i] = d;
+        Tn[i] = T[3 + i] + d;
+      }
+      float mn = min3f(Tn[0].x, Tn[0].y, Tn[1].x);
+      mn = min3f(mn, Tn[1].y, Tn[2].x); mn = min3f(mn, Tn[2].y, Tn[3].x); mn = min3f(mn, Tn[3].y, Tn[4].x);
+      mn = min3f(mn, Tn[4].y, Tn[5].x); mn = min3f(mn, Tn[5].y, Tn[5].y);
+      if (__builtin_expect(!(mn > 0.f), 0)) { // the clamp (:715 / :907), decided per component only where needed
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          const int c = 3 + i;
+          v2 d = dv[i];
+          d.x = (d.x <= -T[c].x) ? -0.9f * T[c].x : d.x;
+          d.y = (d.y <= -T[c].y) ? -0.9f * T[c].y : d.y;
+          Tn[i] = T[c] + d;
         }
-        d.x = (d.x <= -T[c].x) ? -0.9f * T[c].x : d.x; // :715 / :907
-        d.y = (d.y <= -T[c].y) ? -0.9f * T[c].y : d.y;
-        Tn[i] = T[c] + d;
       }
 #pragma unroll
       for (int i = 0; i < P; ++i) T[3 + i] = Tn[i];
