@@ -271,7 +271,10 @@ hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const R
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    static const int wg_per_cu = tuning_int("GREB_STREAM_WGS", 3);
+    // workgroups per CU: 2 measured 5.46-5.64 TB/s against 5.34-5.45 with 3 and 3.9 with 1; a second field pair in
+    // flight per workgroup (two register sets, 144 KB outstanding per CU) measured no better (5.31-5.39): the kernel
+    // runs at the box's HBM rate (1.02-1.05 x its float4 copy), not at a latency limit
+    static const int wg_per_cu = tuning_int("GREB_STREAM_WGS", 2);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = batch < cus * wg_per_cu ? batch : cus * wg_per_cu;
