@@ -45,7 +45,8 @@ constexpr int kThreads = 512;
 // LDS cycle.  With the unpadded stride (48 slots = 0 mod 16) every row started in the same class and the lanes of a
 // pass, which span two to three rows, collided two-way on every read (42 % of the LDS cycles of the round-1 kernel
 // were bank conflicts); with 4 mod 16, rows two apart -- the neighbouring row pairs of a pass -- are offset by 8
-// classes and the 16 lanes of every group fall on distinct classes.
+// classes and the 16 lanes of every group fall on distinct classes.  (The 9.6 KB this costs are those of the polar
+// chains' former Jacobi row buffers plus the slack: the chains exchange their halos by ds_bpermute now.)
 constexpr int RS = 2 * NX + 16;
 // LDS map, in floats
 // X buffers and W carry one all-zero GUARD row below row 0 and above row NY-1: the rows k-2 .. k+2 of any bulk
@@ -57,10 +58,6 @@ constexpr int kOffW = 2 * XB + RS;  // row 0 of W  [NY][NX][{wz_air,wz_vapor}]
 constexpr int kOffWX = 3 * XB;      // [NP]  cu*u   (raw u in rows 0, 47 and in STRICT)
 constexpr int kOffWY = kOffWX + NP; // [NP]  ccy/3*v (raw v ...)
 constexpr int kOffRowK = kOffWY + NP; // [NY][kRowKWords]
-// The Jacobi row buffers of the polar chains live in the GUARD rows of the two X buffers (pole 0: the lower guards,
-// pole 1: the upper ones).  A guard row's content only ever meets a zero weight (W's guard rows stay zero) or, in
-// STRICT, is loaded and not used, so any finite value may sit there; this is what pays for the row padding.
-__device__ __forceinline__ int pole_buf(int pole, int which) { return which * XB + pole * (NY + 1) * RS; }
 constexpr int kLdsFloats = kOffRowK + NY * kRowKWords;
 constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
 
@@ -280,17 +277,19 @@ __host__ __device__ constexpr Pass deal(int wave, int i) {
   constexpr Pass none{kNone, 0};
   // Measured sub-step times of the deals tried (in-kernel stamps, 512 members, cycles at 2.36 GHz; the first line is
   // round 1's deal):   w0 ST0 FT0 | w4 ST1 ; w1 ST2 F1_0 | w5 S1 F1_1 F1_2 ; w6 FT1 F1_3 ; w7 FT2 F1_4   6 299
-  //                    the table below (one F1 pass moved from the younger to the older wave of SIMD 1)        5 838
+  //                    one F1 pass moved from the younger to the older wave of SIMD 1                          5 838
   //                    ... and the other F1 pass of wave 5 moved to wave 6 (pole SIMD)                         6 115
   //                    w0 ST0 F1 F1 | w4 ST1 ; w1 ST2 FT0 | w5 S1 F1 ; w6 FT1 F1 ; w7 FT2 F1                   6 059
   //                    an ST pass on a pole SIMD (w6 ST2), FT1 F1 on w4                                        6 210
+  // With the clamp fast path and the polar halos by ds_bpermute (polar waves 4 700 -> 4 100 busy cycles) the second
+  // line takes 5 501; the table below -- its S1 pass moved to wave 6, wave 5 left with two F1 passes -- 5 416.
   // Static s_setprio 1 on the younger waves, on waves 6/7 or on the polar waves: 6 847 / 6 661 / 5 855 -- the
   // prioritised wave runs its instructions at ~6 cycles each and its partner then runs alone; age order is best.
   constexpr Pass t[8][3] = {
       /* w0 */ {{kST, 0}, {kFT, 0}, none},     /* w1 */ {{kST, 2}, {kF1, 0}, {kF1, 1}},
       /* w2 */ {none, none, none},             /* w3 */ {none, none, none},
-      /* w4 */ {{kST, 1}, none, none},         /* w5 */ {{kS1, 0}, {kF1, 2}, none},
-      /* w6 */ {{kFT, 1}, {kF1, 3}, none},     /* w7 */ {{kFT, 2}, {kF1, 4}, none}};
+      /* w4 */ {{kST, 1}, none, none},         /* w5 */ {{kF1, 2}, {kF1, 3}, none},
+      /* w6 */ {{kFT, 1}, {kS1, 0}, none},     /* w7 */ {{kFT, 2}, {kF1, 4}, none}};
   return t[wave][i];
 }
 __host__ __device__ constexpr int fast_kind(int wave, int i) { return deal(wave, i).kind; }
@@ -381,8 +380,6 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, in
   const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
   const lfloat* Xc = lds + kOffX + cur * XB;
   const lfloat* Wc = lds + kOffW;
-  lfloat* bufA = lds + pole_buf(pole, 0);
-  lfloat* bufB = lds + pole_buf(pole, 1);
   v2 T0w[10], w[10];
   load_win10(Xc + k * RS, l, T0w);
   load_win10(Wc + k * RS, l, w);
@@ -400,6 +397,16 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, in
   }
   const v2 own[2] = {T0w[4], T0w[5]};
   const bool bug_lane = (l == 46); // its 2nd point is longitude xdim-2 (1-based), :881
+  // Between two Jacobi sweeps a lane needs the new values of lanes l-2 .. l+2 (mod 48).  They travel by
+  // ds_bpermute_b32 -- lane to lane through the LDS crossbar, no memory, no bank conflicts, ONE hop -- instead of a
+  // ds_write + s_waitcnt + ds_read round trip through a row buffer behind the bulk waves' read traffic.  The chain
+  // of 8 dependent sweeps is the floor of a sub-step: 4 700 busy cycles per sub-step with the row buffers, 4 100 so.
+  const int am2 = 4 * (l >= 2 ? l - 2 : l + 46), am1 = 4 * (l >= 1 ? l - 1 : 47), ap1 = 4 * (l <= 46 ? l + 1 : 0),
+            ap2 = 4 * (l <= 45 ? l + 2 : l - 46);
+  auto from = [](int addr, v2 x) {
+    return v2{__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x.x))),
+              __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x.y)))};
+  };
   const float uu[2] = {u0, u1};
 
   v2 Th[2][2]; // [diffusion, advection][point]
@@ -413,10 +420,12 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, in
 #pragma unroll
     for (int i = 0; i < 10; ++i) T[i] = T0w[i];
     v2 th[2] = {own[0], own[1]};
-    lfloat* src = bufA;
-    lfloat* dst = bufB;
     for (int tt = 0; tt < time2; ++tt) {
-      if (tt > 0) load_win10(src, l, T);
+      if (tt > 0) { // T[0] and T[9] are not referenced by either stencil
+        T[1] = from(am2, th[1]); T[2] = from(am1, th[0]); T[3] = from(am1, th[1]);
+        T[4] = th[0]; T[5] = th[1];
+        T[6] = from(ap1, th[0]); T[7] = from(ap1, th[1]); T[8] = from(ap2, th[0]);
+      }
       v2 d[2];
       if (STRICT) {
 #pragma unroll
@@ -468,14 +477,8 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, in
           }
         }
       }
-      if (tt + 1 < time2) { // publish for the neighbours' next sweep
-        st_pair2(dst + pair_off(l), th[0], th[1]);
-        wave_lds_sync();
-        lfloat* t = src; src = dst; dst = t;
-      }
     }
     Th[which][0] = th[0]; Th[which][1] = th[1];
-    wave_lds_sync(); // the advection chain reuses the row buffers
   }
 
   // ---- latitudinal terms + update (:585-590, :756-795, :721, :913, :549)
