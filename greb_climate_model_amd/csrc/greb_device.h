@@ -360,7 +360,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // v_rcp/v_log/v_exp/v_sqrt (<= 1-2 ulp): the fluxes they feed enter the state scaled by
 // dt/cap ~ 1e-3..1e-1 K, far below the 1e-4 K tolerance, and they cut the per-point instruction
 // count ~3x (the physics phase is VALU-bound: ~14 divisions, 4 transcendentals per point).
-template <bool EXACT> __device__ __forceinline__ float fdiv(float a, float b) { return EXACT ? a / b : __fdividef(a, b); }
+// (HIP's __fdividef is a plain IEEE division unless the whole file is built with fast-math: ~10 instructions.  The
+// FAST policy wants ONE v_rcp_f32 + one multiply; 19 divisions per point made up 44 % of the point-physics phase.)
+template <bool EXACT> __device__ __forceinline__ float fdiv(float a, float b) { return EXACT ? a / b : a * __builtin_amdgcn_rcpf(b); }
 template <bool EXACT> __device__ __forceinline__ float flog(float x) { return EXACT ? logf(x) : __logf(x); }
 template <bool EXACT> __device__ __forceinline__ float fexp(float x) { return EXACT ? expf(x) : __expf(x); }
 template <bool EXACT> __device__ __forceinline__ float fsqrt(float x) { return EXACT ? sqrtf(x) : __builtin_amdgcn_sqrtf(x); }

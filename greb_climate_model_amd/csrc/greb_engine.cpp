@@ -163,6 +163,7 @@ MemberArgs base_args(greb_engine* e) {
   a.ipx = e->p.ipx; a.ipy = e->p.ipy;
   a.xsw = e->xsw;
   a.stamps = e->stamps;
+  a.dbg = tuning_int("GREB_DEBUG_PHYS", 0);
   if (e->xsw & GREB_X_NO_CIRCULATION) a.nsub = 0; // no transport at all: the tracers come back unchanged
   return a;
 }

@@ -57,6 +57,8 @@ struct MemberArgs {
   // -DGREB_TUNING builds only (null otherwise; the release kernels contain no stamp code): per member and wave, 8
   // cycle totals of one launch -- see tools/stamp_member.py
   unsigned long long* stamps;
+  int dbg;               // -DGREB_TUNING builds only: timing experiments (results wrong): bit 0 point physics without the
+                         // accumulators, bit 1 without the state write-back, bit 2 a single pass instead of three
 };
 
 // fused engine (greb_member.hip): 96x48 with the default sub-cycling layout -- rows 0-9 and 38-47

@@ -707,10 +707,16 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     lfloat* Xf = lds + kOffX + cur * XB;       // the tracers after the 24 sub-steps
     lfloat* red = lds + kOffX + (cur ^ 1) * XB; // idle buffer: annual-mean reduction scratch
     // Each thread takes whole quads (4 consecutive longitudes): every load/store of the ~26
-    // fields a point touches is one dwordx4 and all of a quad's loads are in flight together, so
-    // a step pays ~3 dependent HBM/L2 round trips per thread instead of 9.
+    // fields a point touches is one dwordx4 and all of a quad's loads are in flight together.
+    // 1152 quads on 512 threads: two full passes and a quarter-full one.  Measured with the stamp build
+    // (GREB_DEBUG_PHYS): the first pass of a step costs 13 400 cycles, the other two together 12 500 -- the phase is
+    // VALU-bound (1 170 instructions per quad) plus a cold start of ~5 000 cycles; giving the last 512 points to
+    // all threads as single points (a second code path, cold again) measured 38 700 cycles against 25 900.
 #pragma unroll 1
     for (int qd = tid; qd < NP / 4; qd += kThreads) {
+#ifdef GREB_TUNING
+      if ((a.dbg & 4) && qd >= kThreads) break; // timing experiment: one pass of the three
+#endif
       const q8 xpair = ld8(Xf + (qd / NQ) * RS, qd % NQ);
       f4 oTa, oq, tsm;
       physics_quad<STRICT, FLUX, EXP>(a, P, m, qd, ck, co2, state, acc, corr, comp(xpair, 0), comp(xpair, 1), oTa, oq, tsm);

@@ -53,8 +53,18 @@ __device__ __forceinline__ void physics_quad(const MemberArgs& a, const Phys& P,
     if (FLUX) { vc0 = ld4(a.toclim + p0); vc1 = ld4(a.qclim + off + p0); vc2 = zero4(); }
     else { vc0 = ld4(corr + off + p0); vc1 = ld4(corr + (size_t)kNT * np + off + p0); vc2 = ld4(corr + (size_t)2 * kNT * np + off + p0); }
     f4 acc0, acc1, acc2, acc3, acc4;
+#ifdef GREB_TUNING
+    const bool no_acc = a.dbg & 1, no_wb = a.dbg & 2; // timing experiments (tools/stamp_member.py, GREB_DEBUG_PHYS)
+    const f4 acc5 = no_acc ? zero4() : ld4(acc + 5 * np + p0);
+    if (!FLUX) {
+      if (no_acc) { acc0 = acc1 = acc2 = acc3 = acc4 = zero4(); }
+      else { acc0 = ld4(acc + p0); acc1 = ld4(acc + np + p0); acc2 = ld4(acc + 2 * np + p0); acc3 = ld4(acc + 3 * np + p0); acc4 = ld4(acc + 4 * np + p0); }
+    }
+#else
+    constexpr bool no_acc = false, no_wb = false;
     const f4 acc5 = ld4(acc + 5 * np + p0);
     if (!FLUX) { acc0 = ld4(acc + p0); acc1 = ld4(acc + np + p0); acc2 = ld4(acc + 2 * np + p0); acc3 = ld4(acc + 3 * np + p0); acc4 = ld4(acc + 4 * np + p0); }
+#endif
     f4 vqcl = zero4(), vtclp = zero4(); // experiments only: qclim(ityr) for the linear emissivity, Tclim of the previous step
     if (EXP && (xsw & kXLwLinear)) vqcl = FLUX ? vc1 : ld4(a.qclim + off + p0);
     if (EXP && !FLUX && (xsw & kXSstPlus1)) vtclp = ld4(a.tclim + offm + p0);
@@ -105,8 +115,10 @@ __device__ __forceinline__ void physics_quad(const MemberArgs& a, const Phys& P,
       oalb.v[e] = albedo;
       otsmn.v[e] = acc5.v[e] + Ts0;                                                              // :945
     }
-    st4(state + p0, oTs); st4(state + np + p0, oTa); st4(state + 2 * np + p0, oTo); st4(state + 3 * np + p0, oq);
-    st4(state + 4 * np + p0, ocap);
+    if (!no_wb) {
+      st4(state + p0, oTs); st4(state + np + p0, oTa); st4(state + 2 * np + p0, oTo); st4(state + 3 * np + p0, oq);
+      st4(state + 4 * np + p0, ocap);
+    }
     if (FLUX) {
       st4(corr + off + p0, oTF); st4(corr + (size_t)kNT * np + off + p0, oqF); st4(corr + (size_t)2 * kNT * np + off + p0, oToF);
     } else {
@@ -129,7 +141,7 @@ __device__ __forceinline__ void physics_quad(const MemberArgs& a, const Phys& P,
         st4_nt(rec + p0, r0); st4_nt(rec + np + p0, r1); st4_nt(rec + 2 * np + p0, r2); st4_nt(rec + 3 * np + p0, r3); st4_nt(rec + 4 * np + p0, r4);
         s0 = s1 = s2 = s3 = s4 = zero4();
       }
-      st4(acc + p0, s0); st4(acc + np + p0, s1); st4(acc + 2 * np + p0, s2); st4(acc + 3 * np + p0, s3); st4(acc + 4 * np + p0, s4);
+      if (!no_acc) { st4(acc + p0, s0); st4(acc + np + p0, s1); st4(acc + 2 * np + p0, s2); st4(acc + 3 * np + p0, s3); st4(acc + 4 * np + p0, s4); }
     }
     if (ityr == kNT) { // :948-956
 #pragma clang fp contract(off)
@@ -137,9 +149,9 @@ __device__ __forceinline__ void physics_quad(const MemberArgs& a, const Phys& P,
 #pragma unroll
       for (int e = 0; e < 4; ++e) t.v[e] = otsmn.v[e] / (float)kNT;
       tsmn_mean = t;
-      st4(acc + 5 * np + p0, zero4());
+      if (!no_acc) st4(acc + 5 * np + p0, zero4());
     } else {
-      st4(acc + 5 * np + p0, otsmn);
+      if (!no_acc) st4(acc + 5 * np + p0, otsmn);
     }
   
   oTa_out = oTa; oq_out = oq;
