@@ -711,7 +711,9 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     // 1152 quads on 512 threads: two full passes and a quarter-full one.  Measured with the stamp build
     // (GREB_DEBUG_PHYS): the first pass of a step costs 13 400 cycles, the other two together 12 500 -- the phase is
     // VALU-bound (1 170 instructions per quad) plus a cold start of ~5 000 cycles; giving the last 512 points to
-    // all threads as single points (a second code path, cold again) measured 38 700 cycles against 25 900.
+    // all threads as single points (a second code path) measured 38 700 cycles against 25 900; the per-member operands of
+    // the next pass requested one pass ahead (56 more live VGPRs): 37 100; warm-up loads for the phase's 28 arrays
+    // issued under the sub-steps: no change.  I-cache misses are nil (SQC_ICACHE_MISSES 41 per member-year).
 #pragma unroll 1
     for (int qd = tid; qd < NP / 4; qd += kThreads) {
 #ifdef GREB_TUNING
