@@ -13,8 +13,9 @@
 !   * the console trace                                (src/greb.f90:219,224-225,941,954,1070)
 ! Control crosses into the engine twice per run (flux-correction phase, scenario phase); the
 ! derived fields of greb_model's preamble are computed by the engine's create().
-! An optional fifth group &ENGINE_PAR (strict, device, corr_file, nx, ny) selects reference-order arithmetic,
-! the GPU, a flux-correction cache file and the grid (the reference's is compile-time, src/greb.f90:36).
+! An optional fifth group &ENGINE_PAR (strict, device, corr_file, nx, ny, chunk_years) selects reference-order
+! arithmetic, the GPU, a flux-correction cache file, the grid (the reference's is compile-time, src/greb.f90:36) and
+! how many scenario years are taken per engine call (default: as many as fit a 2 GB host buffer).
 ! An optional sixth group &ENSEMBLE_PAR runs an ENSEMBLE in one engine: in the reference an ensemble is N
 ! processes with N namelists that differ in ens_id (src/greb.f90:153,1064-1068); here the N members share one
 ! greb_engine_create call (the GPU integrates them side by side) and each member's monthly means go to its own
@@ -58,7 +59,8 @@ program greb_host
   namelist / numerics_par / ipx, ipy, time_flux, time_scnr, year0
   namelist / diagnostics_par / output_file, ens_id
   namelist / co2_par / co2_ppm, co2_flux
-  namelist / engine_par / strict, device, corr_file, nx, ny
+  integer :: chunk_years
+  namelist / engine_par / strict, device, corr_file, nx, ny, chunk_years
   ! ---- ensemble
   integer :: n_members
   character(len=10), allocatable :: ens_ids(:)
@@ -98,7 +100,7 @@ program greb_host
   co2_flux = prm%co2_flux
   ipx = 1; ipy = 1; time_flux = 0; time_scnr = 0; year0 = 1940
   output_file = 'output/scenario'; ens_id = ''
-  strict = .false.; device = 0; corr_file = ''; nx = 96; ny = 48
+  strict = .false.; device = 0; corr_file = ''; nx = 96; ny = 48; chunk_years = 0
   n_members = 1; co2_lo = unset; co2_hi = unset
   allocate(ens_ids(max_members), co2_levels(max_members), ens_da_ice(max_members), ens_a_no_ice(max_members), &
        ens_a_cloud(max_members), ens_kappa(max_members))
@@ -264,6 +266,7 @@ program greb_host
      ! years that keep the monthly-mean buffer [member][year][12][5][ny][nx] below ~2 GB
      rec_year = int(12*5, 8)*nx*ny
      chunk = int(max(1_8, min(int(time_scnr, 8), 500000000_8/(rec_year*n_members))))
+     if (chunk_years > 0) chunk = min(chunk_years, time_scnr)   ! &ENGINE_PAR chunk_years: a smaller host buffer
      allocate(monthly(rec_year*chunk*n_members), yearly(2*time_scnr*n_members), units(n_members))
      do m = 1, n_members
         if (n_members == 1) then
