@@ -713,7 +713,9 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     // VALU-bound (1 170 instructions per quad) plus a cold start of ~5 000 cycles; giving the last 512 points to
     // all threads as single points (a second code path) measured 38 700 cycles against 25 900; the per-member operands of
     // the next pass requested one pass ahead (56 more live VGPRs): 37 100; warm-up loads for the phase's 28 arrays
-    // issued under the sub-steps: no change.  I-cache misses are nil (SQC_ICACHE_MISSES 41 per member-year).
+    // issued under the sub-steps: no change; the next step's winds fetched before the phase and stored after it (24 live
+    // VGPRs, wind staging 2 600 -> 250 cycles): the phase itself 35 000.  I-cache misses are nil (SQC_ICACHE_MISSES 41
+    // per member-year).  The phase is very sensitive to its register budget.
 #pragma unroll 1
     for (int qd = tid; qd < NP / 4; qd += kThreads) {
 #ifdef GREB_TUNING
