@@ -662,6 +662,11 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
   float* corr = a.corr + (size_t)a.corr_index[m] * 3 * kNT * NP;
   const RowTables* tab = a.tabs + a.tab_index[m];
 
+#ifdef GREB_TUNING
+  // timing experiment (GREB_DEBUG_PHYS >> 8 = units of 1024 cycles): workgroup b starts (b mod 8) units late, so that
+  // the point-physics phases of the CUs -- the only memory traffic of a step -- do not coincide
+  for (int i = 0; i < (a.dbg >> 8) * (m & 7); ++i) __builtin_amdgcn_s_sleep(16);
+#endif
   Circ<STRICT> circ;
   circ.init(lds, a.wz_air, a.wz_vapor, tab);
   for (int i = tid; i < NP / 4; i += kThreads)
@@ -715,7 +720,9 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     // the next pass requested one pass ahead (56 more live VGPRs): 37 100; warm-up loads for the phase's 28 arrays
     // issued under the sub-steps: no change; the next step's winds fetched before the phase and stored after it (24 live
     // VGPRs, wind staging 2 600 -> 250 cycles): the phase itself 35 000.  I-cache misses are nil (SQC_ICACHE_MISSES 41
-    // per member-year).  The phase is very sensitive to its register budget.
+    // per member-year).  What the slower variants share: vector-memory operations retire in order, so the loop's waits
+    // for its loads also wait for the previous pass's stores; in the form below the compiler gets away with
+    // s_waitcnt vmcnt(6) where the variants end up at vmcnt(0).  (All A/B runs in one gpurun call: boxes differ.)
 #pragma unroll 1
     for (int qd = tid; qd < NP / 4; qd += kThreads) {
 #ifdef GREB_TUNING
