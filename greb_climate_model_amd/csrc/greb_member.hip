@@ -295,6 +295,22 @@ __host__ __device__ constexpr Pass deal(int wave, int i) {
 __host__ __device__ constexpr int fast_kind(int wave, int i) { return deal(wave, i).kind; }
 __host__ __device__ constexpr int fast_index(int wave, int i) { return deal(wave, i).index; } // which pass of its kind
 
+// every pass of every kind is dealt to exactly one wave slot (a deal that drops or doubles a pass would still "run")
+__host__ __device__ constexpr int times_dealt(int kind, int index) {
+  int n = 0;
+  for (int w = 0; w < 8; ++w)
+    for (int i = 0; i < 3; ++i) n += (deal(w, i).kind == kind && deal(w, i).index == index) ? 1 : 0;
+  return n;
+}
+__host__ __device__ constexpr bool deal_is_complete() {
+  for (int p = 0; p < 3; ++p) if (times_dealt(kST, p) != 1 || times_dealt(kFT, p) != 1) return false;
+  for (int p = 0; p < 5; ++p) if (times_dealt(kF1, p) != 1) return false;
+  if (times_dealt(kS1, 0) != 1) return false;
+  for (int i = 0; i < 3; ++i) if (deal(2, i).kind != kNone || deal(3, i).kind != kNone) return false; // the polar waves
+  return true;
+}
+static_assert(deal_is_complete(), "the deal must cover 3 ST, 3 FT, 1 S1 and 5 F1 passes exactly once");
+
 // number of tasks of a pass: 64 = every lane has one
 __host__ __device__ constexpr int pass_tasks(int kind, int index) {
   const int total = kind == kST || kind == kFT ? 8 * NQ : (kind == kS1 ? 2 * NQ : (kind == kF1 ? 12 * NQ : 0));
