@@ -21,6 +21,7 @@ namespace {
 
 constexpr int kPairNx = 384, kPairNq = 96, kPairP = 6;
 static_assert(kPairP == 6, "the chain's min3 reduction is written for six points per lane");
+constexpr int kSplitMinSweeps = 96; // a band's longest diffusion chain is split by tracer from this length on
 constexpr int kPHalf = 4 * kPairNq;  // floats per half-row
 constexpr int kPRow = 2 * kPHalf;    // floats per LDS row (768)
 
@@ -148,6 +149,113 @@ __device__ void pair_chain_row(const lfloat* sT, const lfloat* sW, const lfloat*
   }
 }
 
+// ONE tracer (C = 0: Tair, 1: q) of an iterating row, scalar arithmetic: the longest chain of a latitude band is
+// taken by two waves, one per tracer.  A chain's latency is its instruction count (a lone wave issues one instruction
+// per ~5 cycles, packed or not) and the pair form's sweep is ~1.7x the scalar one's (both components' selects and
+// halo moves, packed instructions contending with whatever shares the SIMD): 225 sweeps take ~65 us as pairs and
+// ~38 us per tracer side by side.  Same coefficient form, same operation order per tracer as pair_chain_row.
+template <int C>
+__device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lfloat* sU, const lfloat* sV, int r0, int k0,
+                                    int k, int ny, const RowK& rk, int lane, float* __restrict__ out_row /* global [nx][2] */) {
+  constexpr int P = kPairP, W = P + 6;
+  auto comp = [](v2 a) { return C == 0 ? a.x : a.y; };
+  const lfloat* Trow = sT + (k - r0) * kPRow;
+  const lfloat* Wrow = sW + (k - r0) * kPRow;
+  float T0[W], w[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    int x = P * lane - 3 + i;
+    x = x < 0 ? x + kPairNx : (x >= kPairNx ? x - kPairNx : x);
+    const int o = ppair_off(x >> 1) + (x & 1) * 2 + C;
+    T0[i] = Trow[o];
+    w[i] = Wrow[o];
+  }
+  float us[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) us[i] = sU[(k - k0) * kPairNx + P * lane + i];
+  const bool bug_lane = lane == 63; // :881
+  const int time2[2] = {__builtin_amdgcn_readfirstlane(rk.dif_time2), __builtin_amdgcn_readfirstlane(rk.adv_time2)};
+  const float cs = rk.dif_cc * 0.05f;
+  float Th[2][P];
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    float K[P][6];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int c = 3 + i;
+      if (which) {
+        float pos, neg;
+        split_sign(us[i], pos, neg);
+        K[i][0] = -pos * w[c - 3]; K[i][1] = (-4.f * pos) * w[c - 2]; K[i][2] = (-10.f * pos) * w[c - 1];
+        K[i][3] = (-10.f * neg) * w[c + 1]; K[i][4] = (-4.f * neg) * w[c + 2]; K[i][5] = -neg * w[c + 3];
+        if (i == P - 3 && bug_lane) { K[i][4] = -neg * w[c + 3]; K[i][5] = -neg * w[c + 3]; }
+      } else {
+        K[i][0] = -cs * w[c - 3]; K[i][1] = (-3.f * cs) * w[c - 2]; K[i][2] = (-6.f * cs) * w[c - 1];
+        K[i][3] = (6.f * cs) * w[c + 1]; K[i][4] = (3.f * cs) * w[c + 2]; K[i][5] = cs * w[c + 3];
+      }
+    }
+    float T[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) T[i] = T0[i];
+    for (int tt = 0; tt < time2[which]; ++tt) {
+      if (tt > 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          T[i] = wave_from_prev(T[P + i]);
+          T[P + 3 + i] = wave_from_next(T[3 + i]);
+        }
+      }
+      float e[W - 1];
+#pragma unroll
+      for (int m = 0; m < W - 1; ++m) e[m] = T[m + 1] - T[m];
+      float Tn[P], dv[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        float d = K[i][0] * e[i];
+#pragma unroll
+        for (int m = 1; m < 6; ++m) d = __builtin_fmaf(K[i][m], e[i + m], d);
+        dv[i] = d;
+        Tn[i] = T[3 + i] + d;
+      }
+      float mn = min3f(Tn[0], Tn[1], Tn[2]);
+      mn = min3f(mn, Tn[3], Tn[4]); mn = min3f(mn, Tn[5], Tn[5]);
+      if (__builtin_expect(!(mn > 0.f), 0)) { // the clamp (:715 / :907), decided per point only where needed
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          const int c = 3 + i;
+          const float d = (dv[i] <= -T[c]) ? -0.9f * T[c] : dv[i];
+          Tn[i] = T[c] + d;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < P; ++i) T[3 + i] = Tn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) Th[which][i] = T[3 + i];
+  }
+  const float am = (k == 1) ? 3.f : 1.f, ap = (k == ny - 2) ? 3.f : 1.f; // :766-769, :784-787 (v is scaled by ccy/3)
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int x = P * lane + i;
+    const int o = ppair_off(x >> 1) + (x & 1) * 2 + C;
+    const float own = T0[3 + i];
+    auto rowv = [&](const lfloat* base, int kk) { return base[(kk - r0) * kPRow + o]; };
+    const float Tm1 = k >= 1 ? rowv(sT, k - 1) : own, Tp1 = k <= ny - 2 ? rowv(sT, k + 1) : own;
+    const float Tm2 = k >= 2 ? rowv(sT, k - 2) : own, Tp2 = k <= ny - 3 ? rowv(sT, k + 2) : own;
+    const float Wm1 = k >= 1 ? rowv(sW, k - 1) : 0.f, Wp1 = k <= ny - 2 ? rowv(sW, k + 1) : 0.f;
+    const float Wm2 = k >= 2 ? rowv(sW, k - 2) : 0.f, Wp2 = k <= ny - 3 ? rowv(sW, k + 2) : 0.f;
+    float vpos, vneg;
+    split_sign(sV[(k - k0) * kPairNx + x], vpos, vneg);
+    const float gm1 = Wm1 * (Tm1 - own), gp1 = Wp1 * (Tp1 - own);
+    const float dm2 = Wm2 * (own - Tm2), dp2 = Wp2 * (own - Tp2);
+    const float ddy = rk.dif_ccy * (gm1 + gp1);
+    const float day = (ap * vneg) * (dp2 - gp1) - (am * vpos) * (dm2 - gm1);
+    const float dd = w[3 + i] * ((Th[0][i] - own) + ddy); // :718, :721
+    const float da = (Th[1][i] - own) + day;              // :910, :913
+    out_row[2 * x + C] = (own + dd) + da;                 // :549
+  }
+}
+
 __global__ __launch_bounds__(256) void sweep_pair_kernel(const float* __restrict__ X2, const float* __restrict__ W2p,
                                                          const float* __restrict__ ug, const float* __restrict__ vg,
                                                          float* __restrict__ Xnew2, const RowTables* __restrict__ tabp,
@@ -185,12 +293,26 @@ __global__ __launch_bounds__(256) void sweep_pair_kernel(const float* __restrict
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // iterating rows: one wave each
+  // iterating rows.  The band's longest chain, if it is long enough to set the length of the launch, is split by
+  // tracer over waves 0 and 1 (scalar arithmetic); the other iterating rows go one wave each to the remaining waves.
+  int ksplit = -1, tmax = kSplitMinSweeps - 1;
+  for (int k = k0; k < k1; ++k) {
+    const int t = tab.dif_time2[k];
+    if (t > tmax) { tmax = t; ksplit = k; }
+  }
   int ci = 0;
   for (int k = k0; k < k1; ++k) {
     const RowK rk = row_consts((const lfloat*)rowk, k);
     if (!(rk.dif_time2 > 1 || rk.adv_time2 > 1)) continue;
-    if ((ci++ & 3) == wave) pair_chain_row(sT, sW, sU, sV, r0, k0, k, ny, rk, lane, Xnew2 + fo + (size_t)k * kPairNx * 2);
+    float* orow = Xnew2 + fo + (size_t)k * kPairNx * 2;
+    if (k == ksplit) {
+      if (wave == 0) pair_chain_row_comp<0>(sT, sW, sU, sV, r0, k0, k, ny, rk, lane, orow);
+      if (wave == 1) pair_chain_row_comp<1>(sT, sW, sU, sV, r0, k0, k, ny, rk, lane, orow);
+    } else if (ksplit >= 0) {
+      if (2 + (ci++ & 1) == wave) pair_chain_row(sT, sW, sU, sV, r0, k0, k, ny, rk, lane, orow);
+    } else if ((ci++ & 3) == wave) {
+      pair_chain_row(sT, sW, sU, sV, r0, k0, k, ny, rk, lane, orow);
+    }
   }
   // single-sweep rows: pair-quads, all threads
   for (int i = threadIdx.x; i < nb * kPairNq; i += 256) {
