@@ -59,6 +59,7 @@ __device__ void pair_chain_row(const lfloat* sT, const lfloat* sW, const lfloat*
   for (int i = 0; i < P; ++i) us[i] = sU[(k - k0) * kPairNx + P * lane + i];
   const bool bug_lane = lane == 63; // its point P-3 is longitude xdim-2 (1-based), src/greb.f90:881
   const int time2[2] = {__builtin_amdgcn_readfirstlane(rk.dif_time2), __builtin_amdgcn_readfirstlane(rk.adv_time2)};
+  if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(3); // greb_stencil.h: the long chains issue first
   const float cs = rk.dif_cc * 0.05f;
   v2 Th[2][P];
 #pragma unroll
@@ -124,6 +125,7 @@ __device__ void pair_chain_row(const lfloat* sT, const lfloat* sW, const lfloat*
     for (int i = 0; i < P; ++i) Th[which][i] = T[3 + i];
   }
   // latitudinal terms: rows k-2 .. k+2 at the own longitudes; rows outside the grid contribute nothing
+  if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
   const float am = (k == 1) ? 3.f : 1.f, ap = (k == ny - 2) ? 3.f : 1.f; // :766-769, :784-787 (v is scaled by ccy/3)
 #pragma unroll
   for (int i = 0; i < P; ++i) {
@@ -175,6 +177,7 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lf
   for (int i = 0; i < P; ++i) us[i] = sU[(k - k0) * kPairNx + P * lane + i];
   const bool bug_lane = lane == 63; // :881
   const int time2[2] = {__builtin_amdgcn_readfirstlane(rk.dif_time2), __builtin_amdgcn_readfirstlane(rk.adv_time2)};
+  if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(3); // greb_stencil.h: the long chains issue first
   const float cs = rk.dif_cc * 0.05f;
   float Th[2][P];
 #pragma unroll
@@ -233,6 +236,7 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lf
 #pragma unroll
     for (int i = 0; i < P; ++i) Th[which][i] = T[3 + i];
   }
+  if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
   const float am = (k == 1) ? 3.f : 1.f, ap = (k == ny - 2) ? 3.f : 1.f; // :766-769, :784-787 (v is scaled by ccy/3)
 #pragma unroll
   for (int i = 0; i < P; ++i) {

@@ -241,6 +241,7 @@ __device__ __forceinline__ float wave_from_next(float x) { // lane l <- lane l+1
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x134 /* wave_rol:1 */, 0xf, 0xf, false));
 }
 
+constexpr int kChainPrioSweeps = 32;
 template <bool STRICT, int P>
 __device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfloat* urow, float cc, int time2,
                                bool is_adv, int lane, lfloat* bufA) {
@@ -256,6 +257,9 @@ __device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfl
 #pragma unroll
   for (int i = 0; i < P; ++i) u[i] = is_adv ? urow[P * lane + i] : 0.f;
   const bool bug_lane = lane == 63; // its point P-3 is longitude xdim-2 (1-based), src/greb.f90:881
+  // the long chains set the length of the launch: they issue ahead of whatever shares their SIMD (measured 39.0 ->
+  // 37.8 us per sub-step launch for one member)
+  if (time2 >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(3);
   float K[P][6]; // FAST: d(c) = sum_m K[c][m] * e[c-3+m]
   if (!STRICT) {
     const float cs = cc * 0.05f;
@@ -326,6 +330,7 @@ __device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfl
 #pragma unroll
     for (int i = 0; i < P; ++i) T[3 + i] = Tn[i];
   }
+  if (time2 >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
   for (int i = 0; i < P; ++i) bufA[P * lane + i] = T[3 + i];
   wave_lds_sync();
