@@ -197,44 +197,10 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lf
         K[i][3] = (6.f * cs) * w[c + 1]; K[i][4] = (3.f * cs) * w[c + 2]; K[i][5] = cs * w[c + 3];
       }
     }
-    float T[W];
+    static_assert(P == 6, "chain_run6 (greb_stencil.h) is written for 6 points per lane");
 #pragma unroll
-    for (int i = 0; i < W; ++i) T[i] = T0[i];
-    for (int tt = 0; tt < time2[which]; ++tt) {
-      if (tt > 0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          T[i] = wave_from_prev(T[P + i]);
-          T[P + 3 + i] = wave_from_next(T[3 + i]);
-        }
-      }
-      float e[W - 1];
-#pragma unroll
-      for (int m = 0; m < W - 1; ++m) e[m] = T[m + 1] - T[m];
-      float Tn[P], dv[P];
-#pragma unroll
-      for (int i = 0; i < P; ++i) {
-        float d = K[i][0] * e[i];
-#pragma unroll
-        for (int m = 1; m < 6; ++m) d = __builtin_fmaf(K[i][m], e[i + m], d);
-        dv[i] = d;
-        Tn[i] = T[3 + i] + d;
-      }
-      float mn = min3f(Tn[0], Tn[1], Tn[2]);
-      mn = min3f(mn, Tn[3], Tn[4]); mn = min3f(mn, Tn[5], Tn[5]);
-      if (__builtin_expect(!(mn > 0.f), 0)) { // the clamp (:715 / :907), decided per point only where needed
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-          const int c = 3 + i;
-          const float d = (dv[i] <= -T[c]) ? -0.9f * T[c] : dv[i];
-          Tn[i] = T[c] + d;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < P; ++i) T[3 + i] = Tn[i];
-    }
-#pragma unroll
-    for (int i = 0; i < P; ++i) Th[which][i] = T[3 + i];
+    for (int i = 0; i < P; ++i) Th[which][i] = T0[3 + i];
+    chain_run6(Th[which], K, time2[which]); // the sweeps: differences as halo, DPP operands, 53 instructions each
   }
   if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
   const float am = (k == 1) ? 3.f : 1.f, ap = (k == ny - 2) ? 3.f : 1.f; // :766-769, :784-787 (v is scaled by ccy/3)
