@@ -197,10 +197,10 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lf
         K[i][3] = (6.f * cs) * w[c + 1]; K[i][4] = (3.f * cs) * w[c + 2]; K[i][5] = cs * w[c + 3];
       }
     }
-    static_assert(P == 6, "chain_run6 (greb_stencil.h) is written for 6 points per lane");
+    static_assert(P == 6, "chain_run6 (greb_chain6.h) is written for 6 points per lane");
 #pragma unroll
     for (int i = 0; i < P; ++i) Th[which][i] = T0[3 + i];
-    chain_run6(Th[which], K, time2[which]); // the sweeps: differences as halo, DPP operands, 53 instructions each
+    chain_run6(Th[which], K, time2[which]); // the sweeps, greb_chain6.h
   }
   if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
   const float am = (k == 1) ? 3.f : 1.f, ap = (k == ny - 2) ? 3.f : 1.f; // :766-769, :784-787 (v is scaled by ccy/3)

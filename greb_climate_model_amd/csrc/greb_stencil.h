@@ -1,6 +1,7 @@
 // greb_stencil.h -- quad-level assembly of the stencil pieces (greb_device.h) shared by the
 // batched sweep kernels (greb_kernels.hip) and the fused member engine (greb_member.hip).
 #pragma once
+#include "greb_chain6.h"
 #include "greb_device.h"
 
 namespace greb {
@@ -239,101 +240,6 @@ __device__ __forceinline__ float wave_from_prev(float x) { // lane l <- lane l-1
 }
 __device__ __forceinline__ float wave_from_next(float x) { // lane l <- lane l+1, lane 63 <- lane 0
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x134 /* wave_rol:1 */, 0xf, 0xf, false));
-}
-
-// One FAST sweep of a 384-point row held 6 points per lane, as the 53 instructions it needs (the compiler's own
-// rendering of the same arithmetic is 65: it packs half of it into v_pk_* -- no cheaper for a lone wave -- and pays for
-// that with register moves, and it keeps every DPP halo as a v_mov of its own).
-//   o[i] = the lane's points, K[i][m] the fixed coefficients: d[i] = sum_m K[i][m] * e[i+m], e[j] = T[j+1] - T[j] over
-//   the window T[0..11] = (prev lane's o[3..5], o[0..5], next lane's o[0..2]); n[i] = o[i] + d[i]; mn = min_i n[i].
-// The halo is carried as DIFFERENCES, not values: e[0], e[1] are the previous lane's e[6], e[7], e[9], e[10] the next
-// lane's e[3], e[4], and they enter as the DPP operand of the v_mul / v_fmac that consumes them (wave_ror/rol:1 --
-// the rotate is the row's periodic boundary); only e[2] and e[8], which straddle a lane boundary, cost a DPP subtract.
-// Same operands and operations, in the same order, as differencing a refreshed T halo: results are bit-identical to
-// that form.  Term m of all six points is issued before term m+1, so no instruction waits on its predecessor and every
-// DPP read is >= 5 instructions behind the write of its source (the assembler does not see hazards inside an asm body).
-__device__ __forceinline__ void chain_sweep6(const float (&o)[6], const float (&K)[6][6], float (&n)[6], float (&d)[6],
-                                             float& mn) {
-  float e2, e3, e4, e5, e6, e7, e8;
-  asm(
-      "v_sub_f32 %[e6], %[o4], %[o3]\n"
-      "v_sub_f32 %[e7], %[o5], %[o4]\n"
-      "v_sub_f32 %[e3], %[o1], %[o0]\n"
-      "v_sub_f32 %[e4], %[o2], %[o1]\n"
-      "v_sub_f32 %[e5], %[o3], %[o2]\n"
-      "v_subrev_f32_dpp %[e2], %[o5], %[o0] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-      "v_sub_f32_dpp %[e8], %[o0], %[o5] wave_rol:1 row_mask:0xf bank_mask:0xf\n"
-      "v_mul_f32_dpp %[d0], %[e6], %[k00] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-      "v_mul_f32_dpp %[d1], %[e7], %[k10] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-      "v_mul_f32 %[d2], %[k20], %[e2]\n"
-      "v_mul_f32 %[d3], %[k30], %[e3]\n"
-      "v_mul_f32 %[d4], %[k40], %[e4]\n"
-      "v_mul_f32 %[d5], %[k50], %[e5]\n"
-      "v_fmac_f32_dpp %[d0], %[e7], %[k01] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32 %[d1], %[k11], %[e2]\n"
-      "v_fmac_f32 %[d2], %[k21], %[e3]\n"
-      "v_fmac_f32 %[d3], %[k31], %[e4]\n"
-      "v_fmac_f32 %[d4], %[k41], %[e5]\n"
-      "v_fmac_f32 %[d5], %[k51], %[e6]\n"
-      "v_fmac_f32 %[d0], %[k02], %[e2]\n"
-      "v_fmac_f32 %[d1], %[k12], %[e3]\n"
-      "v_fmac_f32 %[d2], %[k22], %[e4]\n"
-      "v_fmac_f32 %[d3], %[k32], %[e5]\n"
-      "v_fmac_f32 %[d4], %[k42], %[e6]\n"
-      "v_fmac_f32 %[d5], %[k52], %[e7]\n"
-      "v_fmac_f32 %[d0], %[k03], %[e3]\n"
-      "v_fmac_f32 %[d1], %[k13], %[e4]\n"
-      "v_fmac_f32 %[d2], %[k23], %[e5]\n"
-      "v_fmac_f32 %[d3], %[k33], %[e6]\n"
-      "v_fmac_f32 %[d4], %[k43], %[e7]\n"
-      "v_fmac_f32 %[d5], %[k53], %[e8]\n"
-      "v_fmac_f32 %[d0], %[k04], %[e4]\n"
-      "v_fmac_f32 %[d1], %[k14], %[e5]\n"
-      "v_fmac_f32 %[d2], %[k24], %[e6]\n"
-      "v_fmac_f32 %[d3], %[k34], %[e7]\n"
-      "v_fmac_f32 %[d4], %[k44], %[e8]\n"
-      "v_fmac_f32_dpp %[d5], %[e3], %[k54] wave_rol:1 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32 %[d0], %[k05], %[e5]\n"
-      "v_fmac_f32 %[d1], %[k15], %[e6]\n"
-      "v_fmac_f32 %[d2], %[k25], %[e7]\n"
-      "v_fmac_f32 %[d3], %[k35], %[e8]\n"
-      "v_fmac_f32_dpp %[d4], %[e3], %[k45] wave_rol:1 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32_dpp %[d5], %[e4], %[k55] wave_rol:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32 %[n0], %[o0], %[d0]\n"
-      "v_add_f32 %[n1], %[o1], %[d1]\n"
-      "v_add_f32 %[n2], %[o2], %[d2]\n"
-      "v_add_f32 %[n3], %[o3], %[d3]\n"
-      "v_add_f32 %[n4], %[o4], %[d4]\n"
-      "v_add_f32 %[n5], %[o5], %[d5]\n"
-      "v_min3_f32 %[mn], %[n0], %[n1], %[n2]\n"
-      "v_min3_f32 %[mn], %[mn], %[n3], %[n4]\n"
-      "v_min3_f32 %[mn], %[mn], %[n5], %[n5]\n"
-      : [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [n2] "=&v"(n[2]), [n3] "=&v"(n[3]), [n4] "=&v"(n[4]), [n5] "=&v"(n[5]), [d0] "=&v"(d[0]), [d1] "=&v"(d[1]), [d2] "=&v"(d[2]), [d3] "=&v"(d[3]), [d4] "=&v"(d[4]), [d5] "=&v"(d[5]), [mn] "=&v"(mn), [e2] "=&v"(e2), [e3] "=&v"(e3), [e4] "=&v"(e4), [e5] "=&v"(e5), [e6] "=&v"(e6), [e7] "=&v"(e7), [e8] "=&v"(e8)
-      : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]), [o4] "v"(o[4]), [o5] "v"(o[5]), [k00] "v"(K[0][0]), [k01] "v"(K[0][1]), [k02] "v"(K[0][2]), [k03] "v"(K[0][3]), [k04] "v"(K[0][4]), [k05] "v"(K[0][5]), [k10] "v"(K[1][0]), [k11] "v"(K[1][1]), [k12] "v"(K[1][2]), [k13] "v"(K[1][3]), [k14] "v"(K[1][4]), [k15] "v"(K[1][5]), [k20] "v"(K[2][0]), [k21] "v"(K[2][1]), [k22] "v"(K[2][2]), [k23] "v"(K[2][3]), [k24] "v"(K[2][4]), [k25] "v"(K[2][5]), [k30] "v"(K[3][0]), [k31] "v"(K[3][1]), [k32] "v"(K[3][2]), [k33] "v"(K[3][3]), [k34] "v"(K[3][4]), [k35] "v"(K[3][5]), [k40] "v"(K[4][0]), [k41] "v"(K[4][1]), [k42] "v"(K[4][2]), [k43] "v"(K[4][3]), [k44] "v"(K[4][4]), [k45] "v"(K[4][5]), [k50] "v"(K[5][0]), [k51] "v"(K[5][1]), [k52] "v"(K[5][2]), [k53] "v"(K[5][3]), [k54] "v"(K[5][4]), [k55] "v"(K[5][5]));
-}
-
-// time2 dependent sweeps of chain_sweep6 with the clamp `where(dTxh <= -T1h) dTxh = -0.9*T1h` (:715 / :907): d <= -T
-// implies fl(T + d) <= 0, so the min over the updated values decides whether any lane needs the per-point select.
-// Two sweeps per trip, T -> U -> T, so that no register is copied at the loop edge.
-__device__ __forceinline__ void chain_clamp6(const float (&o)[6], const float (&d)[6], float (&n)[6]) {
-#pragma unroll
-  for (int i = 0; i < 6; ++i) n[i] = o[i] + ((d[i] <= -o[i]) ? -0.9f * o[i] : d[i]);
-}
-__device__ __forceinline__ void chain_run6(float (&T)[6], const float (&K)[6][6], int time2) {
-  float U[6], d[6], mn;
-  int tt = 0;
-  for (; tt + 2 <= time2; tt += 2) {
-    chain_sweep6(T, K, U, d, mn);
-    if (__builtin_expect(!(mn > 0.f), 0)) chain_clamp6(T, d, U); // also taken for a NaN: the reference's comparisons decide
-    chain_sweep6(U, K, T, d, mn);
-    if (__builtin_expect(!(mn > 0.f), 0)) chain_clamp6(U, d, T);
-  }
-  if (tt < time2) {
-    chain_sweep6(T, K, U, d, mn);
-    if (__builtin_expect(!(mn > 0.f), 0)) chain_clamp6(T, d, U);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) T[i] = U[i];
-  }
 }
 
 constexpr int kChainPrioSweeps = 32;
