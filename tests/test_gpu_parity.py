@@ -279,6 +279,42 @@ def test_strict_stencils_bit_exact_g384_vs_reference(eng_mod, oracle_lib, inputs
         assert err.max() <= n_ulp * ulp_T and np.sqrt((err ** 2).mean()) < 0.5 * ulp_T, (name, err.max(), ulp_T)
 
 
+def test_chain_clamp_g384(eng_mod, oracle_lib, inputs384):
+    """The clamp (src/greb.f90:715,907) INSIDE the register-resident 384-point chains: a vapour field with exact zeros
+    and polar spikes makes increments reach -T during the 225 / 82 / 40 ... dependent sweeps of rows 2-12 and 181-191.
+    STRICT bit-exact against the oracle (itself bit-identical to the reference at this grid, routine_g384.npz); FAST --
+    whose sweep is the hand-scheduled body of greb_chain6.h and takes the checked path exactly where the min test
+    fires -- must take the same clamp decisions except at exact ties."""
+    from greb_climate_model_amd import abi, workload
+    p = abi.default_params()
+    Ta, q, ityr = workload.routine_inputs_g384(inputs384)
+    o = oracle_lib.Oracle(inputs384, p)
+    wa, wv = o.field(5).copy(), o.field(6).copy()
+    u, v = inputs384.uclim[ityr - 1], inputs384.vclim[ityr - 1]
+    rng = np.random.default_rng(384)
+    f = np.float32
+    spiky = (q * (rng.random(q.shape) < 0.7)).astype(f)                       # 30 % exact zeros
+    spiky[1, ::7] = f(0.05); spiky[2, 3::5] = f(0.08); spiky[189, 300:] = f(0.03); spiky[190, ::11] = f(0.06)
+    holes = Ta.copy(); holes[1:4, 100:140] = f(0); holes[188:191, ::9] = f(0)  # zeros in the longest chains
+    west = (-np.abs(u) - f(3)).astype(f)
+    n_clamped = 0
+    for X, W, U in ((spiky, wv, u), (spiky, wv, west), (holes, wa, u)):
+        dr, ar, cr = o.diffusion(X, W), o.advection(X, W, u=U, v=v), o.circulation(X, W, u=U, v=v)
+        X2, W2, U2, V2 = X[None], W[None], U[None], v[None]
+        assert np.array_equal(eng_mod.diffusion(X2, W2, p, strict=True)[0], dr)
+        assert np.array_equal(eng_mod.advection(X2, W2, U2, V2, p, strict=True)[0], ar)
+        assert np.array_equal(eng_mod.circulation(X2, W2, U2, V2, p, strict=True)[0], cr)
+        n_clamped += int(np.count_nonzero((X > 0) & (dr / np.maximum(W, f(1e-30)) <= -0.89 * X)))
+        # FAST: one ulp of the state per sweep decision at most, as at 96x48 (test_stencil_edge_cases_strict)
+        scale = float(np.spacing(np.abs(X).max()))
+        for got, ref, n in ((eng_mod.diffusion(X2, W2, p)[0], dr, 2), (eng_mod.advection(X2, W2, U2, V2, p)[0], ar, 2),
+                            (eng_mod.circulation(X2, W2, U2, V2, p)[0], cr, 24)):
+            err = np.abs(got.astype(np.float64) - ref)
+            assert err.max() <= 4e-6 * max(np.abs(ref).max(), 1e-30) + n * scale, (err.max(), scale)
+    o.close()
+    assert n_clamped > 0  # the cases do drive points to the clamp
+
+
 @pytest.mark.parametrize("mode", ["strict", "fast", "pairs"])
 def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
     """BASELINE config 3 in miniature against the REFERENCE compiled at 384x192 (g384_short.npz): 1+2 yr, 2xCO2.
