@@ -24,10 +24,11 @@
 //   the six rows of their column (44 instead of 62 ds_read_b128).  The 46 non-polar rows are the "sub" family
 //   (rows 1-9, 38-46: sub-cycled formulas, one sweep) and the "full" family (rows 10-37).  A PASS is 64 tasks of
 //   one kind, one per lane; FAST: 3 passes of sub row-pairs, 3 of full row-pairs, 1 + 4.5 of single rows,
-//   in both arithmetic modes; dealt statically to six bulk waves (see "The schedule") with
+//   in both arithmetic modes; dealt statically to the seven (STRICT: six) bulk waves (see "The schedule") with
 //   each lane's task addresses computed once per launch.
-//   two polar waves: rows 0 / 47 (8 dependent Jacobi sweeps per diffusion call, src/greb.f90:656-717):
-//   48 lanes x 2 longitudes x (Tair,q), neighbours through an LDS row buffer.
+//   polar rows 0 / 47 (8 dependent Jacobi sweeps per diffusion call, src/greb.f90:656-717): FAST -- ONE wave, each
+//   DPP row of 16 lanes x 6 longitudes one (pole, tracer) chain, neighbours by row rotates (quad_chain_substep);
+//   STRICT -- one wave per pole, 48 lanes x 2 longitudes x (Tair,q), neighbours by ds_bpermute (chain_substep).
 // One s_barrier per sub-step.
 #include <cstdlib>
 
@@ -70,6 +71,9 @@ bool member_layout_supported(const RowTables& t, int nx, int ny) {
     const bool chain = (k == 0 || k == NY - 1);
     if ((t.dif_time2[k] > 1 || t.adv_time2[k] > 1) != chain) return false;
   }
+  // the FAST engine runs both poles' chains in one wavefront with one (scalar) trip count; cos(-lat) = cos(lat)
+  // makes the two rows' constants identical in the reference, so this never fails for its grid
+  if (t.dif_time2[0] != t.dif_time2[NY - 1] || t.adv_time2[0] != t.adv_time2[NY - 1]) return false;
   return true;
 }
 
@@ -263,17 +267,47 @@ struct BulkTasks { TaskAddr t[3]; };
 //   FT  rows (10,11) .. (24,25)                          : 8 pairs x 24 quads = 3 full passes   (306)
 //   S1  rows 9, 38                                       : 48 tasks, one pass                   (223)
 //   F1  rows 26 .. 37                                    : 288 tasks, 4.5 passes                (156)
-// Waves w and w+4 share a SIMD; waves 2 and 3 are the polar waves (a dependent chain of 8 Jacobi sweeps, ~4 800
-// cycles however little else runs).  The SIMD's issue arbiter favours the OLDER wave; the younger one runs in the
+// Waves w and w+4 share a SIMD; the polar rows (a dependent chain of 8 + 1 Jacobi sweeps per sub-step) have their own
+// wave(s): wave 2 in FAST, waves 2 and 3 in STRICT.  The SIMD's issue arbiter favours the OLDER wave; the younger one runs in the
 // slots that leaves, and once the older wave is done the younger runs alone at a single wave's issue rate (one
 // instruction per ~5 cycles at best, ~6-7 with its LDS waits) -- so the older wave of a pair carries the larger
 // share and the two should finish together.  In-kernel stamps (tools/stamp_member.py) give each wave's busy time
 // per sub-step.  The loop is VALU-pipe bound: a packed fp32 instruction occupies the SIMD for ~4.9 cycles (measured,
-// tools/ubench/valu_rate.hip; a scalar one ~2.3-2.7), which puts the work dealt to SIMD 0 at ~5 160 pipe cycles of
-// the 5 620 it takes.
+// tools/ubench/valu_rate.hip; a scalar one ~2.3-2.7).
 enum { kNone = 0, kS1 = 1, kF1 = 2, kST = 3, kFT = 4 };
 struct Pass { int kind, index; };
-__host__ __device__ constexpr Pass deal(int wave, int i) {
+// FAST: wave 2 alone runs all four polar chains (quad_chain_substep: 36-instruction sweeps, ~3 050 busy cycles per
+// sub-step where two waves took ~4 400 each), wave 3 is a seventh bulk wave.  The chain wave is the OLDER wave of
+// SIMD 2 and issues one instruction every ~5 cycles for as long as it runs, so its partner gets little of the pipe
+// until it is done.  Measured sub-step times (tools/deal_search.py: in-kernel stamps, 512 members, one gpurun call;
+// slots w0 w1 w3 | w4 w5 w6 w7, S = ST, T = FT, H = S1, F = F1):
+//     S0+F0 S2+H  T2+F1+F2 | S1    T0    T1+F3 F4      4 932   <- the table below
+//     S0+F0 S1+H  T2+F1+F2 | S2    T0    T1+F3 F4      4 929
+//     S0+F0 S2+H  T2+F1    | S1    T0    T1+F3 F2+F4   4 975
+//     S0+F0 S2+F1 T2+H+F2  | S1    T0    T1+F3 F4      4 974
+//     S0+F0 S2+H  T2+F1+F2 | S1    T0    T1    F3+F4   5 070   (wave 7 waits behind wave 3's three passes)
+//     S0+F0 S2+T0 H+F1+F2  | S1    T2    T1    F3+F4   5 094
+//     S0+H  S2+F0 T2+F1+F2 | S1    T0    T1+F3 F4      5 103
+//     S0    S2+H  T2+F1    | S1+F0 T0    T1+F2 F3+F4   5 273
+//     S0+F0 S2+H  F1+F2+F3 | S1    T0    T1    T2+F4   5 509
+//     S0+F0 S2+H  T2+F1+F2 | S1    T1+F3 T0    F4      5 647
+//     S0    S2+F0 H+F1+F2  | S1    T0    T1+T2 F3+F4   5 988   (two FT passes behind the chain wave)
+// With it the busiest wave of each SIMD is busy 4 470 / 4 580 / 4 760 / 4 290 cycles: within 5 % of a perfect balance.
+__host__ __device__ constexpr Pass deal_fast(int wave, int i) {
+  constexpr Pass none{kNone, 0};
+#if defined(GREB_TUNING) && defined(GREB_DEAL_FAST) // tools/deal_search.py: a deal given on the compiler command line
+  constexpr Pass t[8][3] = {GREB_DEAL_FAST};
+#else
+  constexpr Pass t[8][3] = {
+      /* w0 */ {{kST, 0}, {kF1, 0}, none},     /* w1 */ {{kST, 2}, {kS1, 0}, none},
+      /* w2 */ {none, none, none},             /* w3 */ {{kFT, 2}, {kF1, 1}, {kF1, 2}},
+      /* w4 */ {{kST, 1}, none, none},         /* w5 */ {{kFT, 0}, none, none},
+      /* w6 */ {{kFT, 1}, {kF1, 3}, none},     /* w7 */ {{kF1, 4}, none, none}};
+#endif
+  return t[wave][i];
+}
+// STRICT: waves 2 and 3 are the polar waves (chain_substep, one pole each)
+__host__ __device__ constexpr Pass deal_strict(int wave, int i) {
   constexpr Pass none{kNone, 0};
   // Measured sub-step times of the deals tried (in-kernel stamps, 512 members, cycles at 2.36 GHz; the first line is
   // round 1's deal):   w0 ST0 FT0 | w4 ST1 ; w1 ST2 F1_0 | w5 S1 F1_1 F1_2 ; w6 FT1 F1_3 ; w7 FT2 F1_4   6 299
@@ -292,24 +326,30 @@ __host__ __device__ constexpr Pass deal(int wave, int i) {
       /* w6 */ {{kFT, 1}, {kS1, 0}, none},     /* w7 */ {{kFT, 2}, {kF1, 4}, none}};
   return t[wave][i];
 }
-__host__ __device__ constexpr int fast_kind(int wave, int i) { return deal(wave, i).kind; }
-__host__ __device__ constexpr int fast_index(int wave, int i) { return deal(wave, i).index; } // which pass of its kind
+template <bool STRICT>
+__host__ __device__ constexpr Pass deal(int wave, int i) { return STRICT ? deal_strict(wave, i) : deal_fast(wave, i); }
+template <bool STRICT>
+__host__ __device__ constexpr bool is_polar_wave(int wave) { return wave == 2 || (STRICT && wave == 3); }
 
 // every pass of every kind is dealt to exactly one wave slot (a deal that drops or doubles a pass would still "run")
+template <bool STRICT>
 __host__ __device__ constexpr int times_dealt(int kind, int index) {
   int n = 0;
   for (int w = 0; w < 8; ++w)
-    for (int i = 0; i < 3; ++i) n += (deal(w, i).kind == kind && deal(w, i).index == index) ? 1 : 0;
+    for (int i = 0; i < 3; ++i) n += (deal<STRICT>(w, i).kind == kind && deal<STRICT>(w, i).index == index) ? 1 : 0;
   return n;
 }
+template <bool STRICT>
 __host__ __device__ constexpr bool deal_is_complete() {
-  for (int p = 0; p < 3; ++p) if (times_dealt(kST, p) != 1 || times_dealt(kFT, p) != 1) return false;
-  for (int p = 0; p < 5; ++p) if (times_dealt(kF1, p) != 1) return false;
-  if (times_dealt(kS1, 0) != 1) return false;
-  for (int i = 0; i < 3; ++i) if (deal(2, i).kind != kNone || deal(3, i).kind != kNone) return false; // the polar waves
+  for (int p = 0; p < 3; ++p) if (times_dealt<STRICT>(kST, p) != 1 || times_dealt<STRICT>(kFT, p) != 1) return false;
+  for (int p = 0; p < 5; ++p) if (times_dealt<STRICT>(kF1, p) != 1) return false;
+  if (times_dealt<STRICT>(kS1, 0) != 1) return false;
+  for (int w = 0; w < 8; ++w)
+    for (int i = 0; i < 3; ++i) if (is_polar_wave<STRICT>(w) && deal<STRICT>(w, i).kind != kNone) return false;
   return true;
 }
-static_assert(deal_is_complete(), "the deal must cover 3 ST, 3 FT, 1 S1 and 5 F1 passes exactly once");
+static_assert(deal_is_complete<true>() && deal_is_complete<false>(),
+              "a deal must cover 3 ST, 3 FT, 1 S1 and 5 F1 passes exactly once");
 
 // number of tasks of a pass: 64 = every lane has one
 __host__ __device__ constexpr int pass_tasks(int kind, int index) {
@@ -327,7 +367,7 @@ __device__ __forceinline__ BulkTasks make_tasks(int wave, int lane) {
   for (int i = 0; i < 3; ++i) {
     int k = 1, q = 0, valid = 0;
     {
-      const int kind = fast_kind(wave, i), t = fast_index(wave, i) * 64 + lane;
+      const int kind = deal<STRICT>(wave, i).kind, t = deal<STRICT>(wave, i).index * 64 + lane;
       const int r = t / NQ;
       q = t % NQ;
       // row order: consecutive r of a pass sit two rows (= 8 slot classes) apart wherever the rows allow it
@@ -353,7 +393,7 @@ __device__ __forceinline__ BulkTasks make_tasks(int wave, int lane) {
 // every bulk wave ~100 issue slots per sub-step)
 template <bool STRICT, int SLOT, int I>
 __device__ __forceinline__ void bulk_task(lfloat* lds, int cur, const BulkTasks& tasks, int dbg, bool calm_q) {
-  constexpr int kind = fast_kind(SLOT, I), ntask = pass_tasks(kind, fast_index(SLOT, I));
+  constexpr int kind = deal<STRICT>(SLOT, I).kind, ntask = pass_tasks(kind, deal<STRICT>(SLOT, I).index);
   if constexpr (kind != kNone && ntask > 0) {
     if (ntask < 64 && tasks.t[I].kq < 0) return; // partial pass: lanes without a task
     if constexpr (kind == kS1) { if (!(dbg & 1)) row_task<STRICT, true>(lds, cur, tasks.t[I], calm_q); }
@@ -370,7 +410,7 @@ __device__ __forceinline__ void bulk_substep(lfloat* lds, int cur, const BulkTas
 }
 
 // ---------------------------------------------------------------------------------------------
-// polar rows: one wave per pole, 48 lanes x 2 longitudes x (Tair,q)
+// polar rows, STRICT: one wave per pole, 48 lanes x 2 longitudes x (Tair,q), the reference's expression trees
 // ---------------------------------------------------------------------------------------------
 // float offset, inside a [half][quad][4] row, of the longitude pair (2l, 2l+1)
 __device__ __forceinline__ int pair_off(int l) { return (l & 1) * kHalfRow + (l >> 1) * 4; }
@@ -389,8 +429,7 @@ __device__ __forceinline__ void st_pair2(lfloat* p, v2 a, v2 b) {
   *(__attribute__((address_space(3))) vfloat4*)p = x;
 }
 
-template <bool STRICT>
-__device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, int l /* lane */, bool calm_q = false) {
+__device__ __forceinline__ void chain_substep_strict(lfloat* lds, int cur, int pole, int l /* lane */, bool calm_q = false) {
   if (l >= 48) return; // idle lanes (no workgroup barrier inside this function)
   const int k = pole ? NY - 1 : 0;
   const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
@@ -442,56 +481,15 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, in
         T[4] = th[0]; T[5] = th[1];
         T[6] = from(ap1, th[0]); T[7] = from(ap1, th[1]); T[8] = from(ap2, th[0]);
       }
-      v2 d[2];
-      if (STRICT) {
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+      for (int pt = 0; pt < 2; ++pt) {
 #pragma clang fp contract(off)
-          const int c = 4 + pt;
-          v2 dd;
-          if (which) dd = adv_lon_sub_point_strict(T, w, uu[pt], cc, c, bug_lane && pt == 1);
-          else dd = div20(cc * dif_S_strict(T, w, c));
-          dd = clamp_e(dd, T[c]); // :715 / :907
-          th[pt] = T[c] + dd;
-        }
-      } else {
-        v2 e[8], Pp[8], Pm[8];
-#pragma unroll
-        for (int m = 1; m <= 7; ++m) {
-          e[m] = T[m + 1] - T[m];
-          if (m >= 4) Pp[m] = w[m + 1] * e[m];
-          if (m <= 4) Pm[m] = w[m] * e[m];
-        }
-        const float cs = cc * 0.05f;
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-          const int c = 4 + pt;
-          if (which) {
-            const float um = cs * fmaxf(uu[pt], 0.f), up = cs * fminf(uu[pt], 0.f);
-            const v2 am = 10.f * Pm[c - 1] + (4.f * Pm[c - 2] + Pm[c - 3]);
-            v2 ap = 10.f * Pp[c] + (4.f * Pp[c + 1] + Pp[c + 2]);
-            if (pt == 1) {
-              const v2 bug = 10.f * Pp[c] - w[c + 3] * (T[c + 1] - T[c + 3]);
-              ap = bug_lane ? bug : ap;
-            }
-            d[pt] = -up * ap - um * am;
-          } else {
-            const v2 a = Pp[c] - Pm[c - 1], b = Pp[c + 1] - Pm[c - 2], g = Pp[c + 2] - Pm[c - 3];
-            d[pt] = cs * (6.f * a + (3.f * b + g));
-          }
-          th[pt] = T[c] + d[pt];
-        }
-        // the clamp (:715 / :907) as in substep_pair: one min decides whether any component needs the select
-        if (__builtin_expect(!(min3f(min3f(th[0].x, th[0].y, th[1].x), th[1].y, th[1].y) > 0.f), 0)) {
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt) {
-            const int c = 4 + pt;
-            v2 dd = d[pt];
-            dd.x = (dd.x <= -T[c].x) ? -0.9f * T[c].x : dd.x;
-            dd.y = (dd.y <= -T[c].y) ? -0.9f * T[c].y : dd.y;
-            th[pt] = T[c] + dd;
-          }
-        }
+        const int c = 4 + pt;
+        v2 dd;
+        if (which) dd = adv_lon_sub_point_strict(T, w, uu[pt], cc, c, bug_lane && pt == 1);
+        else dd = div20(cc * dif_S_strict(T, w, c));
+        dd = clamp_e(dd, T[c]); // :715 / :907
+        th[pt] = T[c] + dd;
       }
     }
     Th[which][0] = th[0]; Th[which][1] = th[1];
@@ -502,39 +500,122 @@ __device__ __forceinline__ void chain_substep(lfloat* lds, int cur, int pole, in
   const float vv[2] = {v0, v1};
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt) {
-    if (STRICT) {
 #pragma clang fp contract(off)
-      const v2 t0 = own[pt], w0 = w[4 + pt], a1 = T1[pt], a2 = T2[pt], b1 = W1[pt], b2 = W2[pt];
-      const float vm = split_m(vv[pt]), vp = split_p(vv[pt]);
-      v2 dTy, aTy;
-      if (pole == 0) {
-        dTy = rk.dif_ccy * b1 * (-t0 + a1);                                        // :589
-        aTy = div3(rk.adv_ccy * (vp * (b1 * (t0 - a1) + b2 * (t0 - a2))));         // :759-761
-      } else {
-        dTy = rk.dif_ccy * b1 * (a1 - t0);                                         // :590
-        aTy = div3(rk.adv_ccy * (-vm * (b1 * (t0 - a1) + b2 * (t0 - a2))));        // :792-794
-      }
-      const v2 dd = w0 * ((Th[0][pt] - t0) + dTy); // :718, :721
-      const v2 da = (Th[1][pt] - t0) + aTy;        // :910, :913
-      const v2 xd = t0 + dd;
-      v2 x = xd + da;                              // :549
-      if (calm_q) x.y = xd.y;                      // orig :562
-      xn[pt] = x;
+    const v2 t0 = own[pt], w0 = w[4 + pt], a1 = T1[pt], a2 = T2[pt], b1 = W1[pt], b2 = W2[pt];
+    const float vm = split_m(vv[pt]), vp = split_p(vv[pt]);
+    v2 dTy, aTy;
+    if (pole == 0) {
+      dTy = rk.dif_ccy * b1 * (-t0 + a1);                                        // :589
+      aTy = div3(rk.adv_ccy * (vp * (b1 * (t0 - a1) + b2 * (t0 - a2))));         // :759-761
     } else {
-      const float third = rk.adv_ccy * (1.f / 3.f);
-      // pole 0: only the v<0 part couples (rows 1,2); pole 1: only the v>=0 part (rows 46,45)
-      const float cv = pole == 0 ? third * fminf(vv[pt], 0.f) : -third * fmaxf(vv[pt], 0.f);
-      const v2 g1 = W1[pt] * (T1[pt] - own[pt]);
-      const v2 d2 = W2[pt] * (own[pt] - T2[pt]);
-      const v2 ddy = rk.dif_ccy * g1;
-      const v2 day = cv * (d2 - g1);
-      const v2 dd = w[4 + pt] * ((Th[0][pt] - own[pt]) + ddy);
-      v2 da = (Th[1][pt] - own[pt]) + day;
-      if (calm_q) da.y = 0.f;
-      xn[pt] = (own[pt] + dd) + da;
+      dTy = rk.dif_ccy * b1 * (a1 - t0);                                         // :590
+      aTy = div3(rk.adv_ccy * (-vm * (b1 * (t0 - a1) + b2 * (t0 - a2))));        // :792-794
     }
+    const v2 dd = w0 * ((Th[0][pt] - t0) + dTy); // :718, :721
+    const v2 da = (Th[1][pt] - t0) + aTy;        // :910, :913
+    const v2 xd = t0 + dd;
+    v2 x = xd + da;                              // :549
+    if (calm_q) x.y = xd.y;                      // orig :562
+    xn[pt] = x;
   }
   st_pair2(lds + kOffX + (cur ^ 1) * XB + k * RS + pair_off(l), xn[0], xn[1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST polar rows: all four chains -- (pole, tracer) -- in ONE wave
+// ---------------------------------------------------------------------------------------------
+// A DPP row of 16 lanes x 6 points is one 96-point latitude circle whose periodic boundary is the row rotate
+// (row_ror:1 / row_ror:15), so the four rows of a wavefront hold the four polar chains of a member: lanes 0-15
+// (south pole, Tair), 16-31 (south, q), 32-47 (north, Tair), 48-63 (north, q).  The sweeps are greb_chain6.h's
+// (36 instructions for all four chains; the earlier form -- one wave per pole, 48 lanes x 2 points x (Tair,q), halos
+// by 12 ds_bpermute per sweep -- needed ~45 per pole and waited for the LDS crossbar in every one of the 9 sweeps:
+// 4 400 busy cycles per sub-step on two waves, now ~2 100 on one).  The coefficients of the diffusion chain are fixed
+// for the run and those of the advection sweep for the model step; both are rebuilt per circulation call so that
+// nothing of this lives across the point-physics phase.
+struct QuadChain {
+  ChainK kd, ka;             // d[i] = sum_m K[i][m] e[i+m] (greb_chain6.h): zonal diffusion, zonal advection
+  float w0[6], W1[6], W2[6]; // weights of the own row and of the two rows towards the interior
+  float cv[6];               // the latitudinal advection coefficient of the point: (ccy/3) min(v,0) south, -(ccy/3) max(v,0) north
+  float ccy;                 // dif_ccy
+  int at[3];                 // float offsets, within a row, of the lane's three longitude pairs (+ its tracer)
+  int row[3];                // float offsets, within a guarded buffer, of rows k, k1, k2
+  int time2_dif, time2_adv;
+  bool calm;                 // vapour lane of an experiment that diffuses vapour without advecting it
+};
+
+__device__ __forceinline__ void quad_chain_setup(const lfloat* lds, int lane, bool calm_q, QuadChain& c) {
+  const int r = lane >> 4, j = lane & 15, pole = r >> 1, C = r & 1;
+  const int k = pole ? NY - 1 : 0, k1 = pole ? k - 1 : k + 1, k2 = pole ? k - 2 : k + 2; // towards the interior
+  const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
+  c.time2_dif = rk.dif_time2; c.time2_adv = rk.adv_time2; c.ccy = rk.dif_ccy;
+  c.calm = calm_q && C == 1;
+  c.row[0] = k * RS; c.row[1] = k1 * RS; c.row[2] = k2 * RS;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) c.at[t] = pair_off(3 * j + t) + C;
+  const lfloat* Wc = lds + kOffW;
+  // (static_for: compile-time indices from the start -- arrays indexed by the variable of a `#pragma unroll` loop are
+  // still dynamically indexed when the compiler decides what may live in registers)
+  float w[12]; // longitudes 6j-3 .. 6j+8
+  static_for<12>([&](auto I) {
+    constexpr int i = I;
+    int x = 6 * j - 3 + i;
+    x = x < 0 ? x + NX : (x >= NX ? x - NX : x);
+    w[i] = Wc[c.row[0] + pair_off(x >> 1) + (x & 1) * 2 + C];
+  });
+  const float third = rk.adv_ccy * (1.f / 3.f), csd = rk.dif_cc * 0.05f, csa = rk.adv_cc * 0.05f;
+  float Kd[6][6], Ka[6][6];
+  static_for<6>([&](auto I) {
+    constexpr int i = I, p = 3 + i;
+    const int o = c.at[i >> 1] + (i & 1) * 2;
+    c.w0[i] = w[p];
+    c.W1[i] = Wc[c.row[1] + o];
+    c.W2[i] = Wc[c.row[2] + o];
+    const float u = lds[kOffWX + k * NX + 6 * j + i], v = lds[kOffWY + k * NX + 6 * j + i]; // raw winds in the polar rows
+    // south pole: only the v<0 part couples (rows 1,2); north pole: only the v>=0 part (rows 46,45)  (:759-761, :792-794)
+    c.cv[i] = pole == 0 ? third * fminf(v, 0.f) : -third * fmaxf(v, 0.f);
+    // 6(Pp[c] - Pm[c-1]) + 3(Pp[c+1] - Pm[c-2]) + (Pp[c+2] - Pm[c-3]), :595-600 in edge-flux form
+    Kd[i][0] = -csd * w[p - 3]; Kd[i][1] = (-3.f * csd) * w[p - 2]; Kd[i][2] = (-6.f * csd) * w[p - 1];
+    Kd[i][3] = (6.f * csd) * w[p + 1]; Kd[i][4] = (3.f * csd) * w[p + 2]; Kd[i][5] = csd * w[p + 3];
+    // -up (10 Pp[c] + 4 Pp[c+1] + Pp[c+2]) - um (10 Pm[c-1] + 4 Pm[c-2] + Pm[c-3]), :845-851
+    const float um = csa * fmaxf(u, 0.f), up = csa * fminf(u, 0.f);
+    Ka[i][0] = -um * w[p - 3]; Ka[i][1] = (-4.f * um) * w[p - 2]; Ka[i][2] = (-10.f * um) * w[p - 1];
+    Ka[i][3] = (-10.f * up) * w[p + 1]; Ka[i][4] = (-4.f * up) * w[p + 2]; Ka[i][5] = -up * w[p + 3];
+    if (i == 3 && j == 15) { // longitude xdim-2 (1-based), :881: the 4* term vanishes, the 1* term is w(1)*(T(xdim-1)-T(1))
+      Ka[i][4] = -up * w[p + 3]; Ka[i][5] = -up * w[p + 3];
+    }
+  });
+  c.kd = chain_pack(Kd);
+  c.ka = chain_pack(Ka);
+}
+
+__device__ __forceinline__ void quad_chain_substep(lfloat* lds, int cur, QuadChain& c) {
+  const lfloat* Xc = lds + kOffX + cur * XB;
+  float own[6], T1[6], T2[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int o = c.at[i >> 1] + (i & 1) * 2;
+    own[i] = Xc[c.row[0] + o];
+    T1[i] = Xc[c.row[1] + o];
+    T2[i] = Xc[c.row[2] + o];
+  }
+  float Td[6], Ta[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { Td[i] = own[i]; Ta[i] = own[i]; }
+  chain_run6<true>(Td, c.kd, c.time2_dif); // :656-717
+  chain_run6<true>(Ta, c.ka, c.time2_adv); // :861-909 (one sweep at this grid)
+  // ---- latitudinal terms + update (:585-590, :756-795, :721, :913, :549)
+  lfloat* out = lds + kOffX + (cur ^ 1) * XB + c.row[0];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const float g1 = c.W1[i] * (T1[i] - own[i]);
+    const float d2 = c.W2[i] * (own[i] - T2[i]);
+    const float ddy = c.ccy * g1;
+    const float day = c.cv[i] * (d2 - g1);
+    const float dd = c.w0[i] * ((Td[i] - own[i]) + ddy);
+    float da = (Ta[i] - own[i]) + day;
+    if (c.calm) da = 0.f; // orig :562
+    out[c.at[i >> 1] + (i & 1) * 2] = (own[i] + dd) + da;
+  }
 }
 
 // stage this step's winds (src/greb.f90:203-216, 732): raw for STRICT and for the polar rows,
@@ -582,14 +663,18 @@ struct Circ {
   ) {
     // the lane's task addresses: derived once per circulation call (not per launch -- values that live across the
     // point-physics phase, where the register pressure peaks, come back as scratch reloads inside this loop)
+    constexpr bool kPolar = is_polar_wave<STRICT>(WAVE);
     BulkTasks tasks;
-    if constexpr (WAVE != 2 && WAVE != 3) tasks = make_tasks<STRICT>(WAVE, lane);
+    QuadChain quad;
+    if constexpr (!kPolar) tasks = make_tasks<STRICT>(WAVE, lane);
+    else if constexpr (!STRICT) quad_chain_setup(lds, lane, calm_q, quad);
 #pragma unroll 1
     for (int tt = 0; tt < nsub; ++tt) {
 #ifdef GREB_TUNING
       const unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 #endif
-      if constexpr (WAVE == 2 || WAVE == 3) { if (!(dbg & 4)) chain_substep<STRICT>(lds, cur, WAVE - 2, lane, calm_q); }
+      if constexpr (kPolar && STRICT) { if (!(dbg & 4)) chain_substep_strict(lds, cur, WAVE - 2, lane, calm_q); }
+      else if constexpr (kPolar) { if (!(dbg & 4)) quad_chain_substep(lds, cur, quad); }
       else bulk_substep<STRICT, WAVE>(lds, cur, tasks, dbg, calm_q);
 #ifdef GREB_TUNING
       if (stamp) busy += __builtin_amdgcn_s_memtime() - t0;

@@ -200,7 +200,7 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lf
     static_assert(P == 6, "chain_run6 (greb_chain6.h) is written for 6 points per lane");
 #pragma unroll
     for (int i = 0; i < P; ++i) Th[which][i] = T0[3 + i];
-    chain_run6(Th[which], K, time2[which]); // the sweeps, greb_chain6.h
+    chain_run6<false>(Th[which], chain_pack(K), time2[which]); // the sweeps, greb_chain6.h
   }
   if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
   const float am = (k == 1) ? 3.f : 1.f, ap = (k == ny - 2) ? 3.f : 1.f; // :766-769, :784-787 (v is scaled by ccy/3)

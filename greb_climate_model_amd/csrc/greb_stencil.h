@@ -310,7 +310,7 @@ __device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfl
     float own[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) own[i] = T[3 + i];
-    chain_run6(own, K, time2);
+    chain_run6<false>(own, chain_pack(K), time2);
 #pragma unroll
     for (int i = 0; i < 6; ++i) T[3 + i] = own[i];
   }

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Deal experiments for the fused member kernel's FAST schedule (greb_member.hip: deal_fast).
+
+  python tools/deal_search.py build          here (no GPU): one -DGREB_TUNING library per candidate deal under
+                                             greb_climate_model_amd/variants/ (git-ignored, travels with gpurun)
+  python tools/deal_search.py run [members]  on the GPU box: tools/stamp_member.py for every built variant, one line each
+
+A deal is written as seven wave slots "w0 w1 w3 w4 w5 w6 w7" (wave 2 runs the polar chains), each a '+'-joined list of
+passes: S0..S2 = ST (two sub-cycled rows), T0..T2 = FT (two full rows), H = S1, F0..F4 = F1, '-' = idle."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VARDIR = os.path.join(ROOT, "greb_climate_model_amd", "variants")
+
+DEALS = {
+    "c":     "S0+F0 S2+H  T2+F1+F2 S1 T0 T1+F3 F4",
+    "c2":    "S0+F0 S2+H  T2+F1    S1 T0 T1+F3 F2+F4",
+    "c6":    "S0+F0 S2+F1 T2+H+F2  S1 T0 T1+F3 F4",
+    "c7":    "S0+H  S2+F0 T2+F1+F2 S1 T0 T1+F3 F4",
+    "c8":    "S0+F0 S2+H  T2+F1+F2 S1 T1+F3 T0 F4",
+    "c9":    "S0+F0 S2+H  T1+F1+F2 S1 T0 T2+F3 F4",
+    "c10":   "S0+F0 S1+H  T2+F1+F2 S2 T0 T1+F3 F4",
+}
+
+
+def table(deal: str) -> str:
+    slots = deal.split()
+    assert len(slots) == 7, deal
+    waves = slots[:2] + ["-"] + slots[2:]
+    rows = []
+    for w in waves:
+        ps = [] if w == "-" else w.split("+")
+        assert len(ps) <= 3, w
+        cells = []
+        for x in ps:
+            kind = {"S": "kST", "T": "kFT", "H": "kS1", "F": "kF1"}[x[0]]
+            cells.append("{%s,%d}" % (kind, int(x[1:]) if len(x) > 1 else 0))
+        cells += ["{kNone,0}"] * (3 - len(cells))
+        rows.append("{" + ",".join(cells) + "}")
+    return ",".join(rows)
+
+
+def build_one(name: str) -> str:
+    from greb_climate_model_amd import build
+    out = os.path.join(VARDIR, f"libgreb_hip_deal_{name}.so")
+    cmd = [build.hipcc(), *build.HIPCC_FLAGS, "-DGREB_TUNING", "-DGREB_DEAL_FAST=" + table(DEALS[name]), "-o", out,
+           *[os.path.join(build.CSRC, s) for s in build.SOURCES]]
+    subprocess.run(cmd, check=True, cwd=build.CSRC, stdout=subprocess.DEVNULL)
+    return out
+
+
+def main() -> None:
+    mode = sys.argv[1] if len(sys.argv) > 1 else "build"
+    names = [n for n in (sys.argv[3:] if mode == "run" else sys.argv[2:]) if n in DEALS] or list(DEALS)
+    if mode == "build":
+        os.makedirs(VARDIR, exist_ok=True)
+        with ThreadPoolExecutor(4) as ex:
+            for out in ex.map(build_one, names):
+                print("built", os.path.relpath(out, ROOT))
+        return
+    members = sys.argv[2] if len(sys.argv) > 2 else "512"
+    for n in names:
+        lib = os.path.join(VARDIR, f"libgreb_hip_deal_{n}.so")
+        if not os.path.exists(lib):
+            continue
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stamp_member.py"), members, "2"],
+                           env=dict(os.environ, GREB_LIB=lib), capture_output=True, text=True)
+        sub = [l for l in r.stdout.splitlines() if l.startswith("sub-step")]
+        busy = [l.split("busy")[1].split("cyc")[0].strip() for l in r.stdout.splitlines() if "busy" in l and "wave" in l]
+        print(f"{n:6s} {DEALS[n]:48s} {sub[0] if sub else r.stderr[-200:]}  busy {' '.join(busy)}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
