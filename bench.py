@@ -256,7 +256,7 @@ def main():
                                     "achieved_tflops_per_gpu": round(value / world * gflop_my / 1e3, 2),
                                     "peak_fp32_vector_tflops": 157.3,
                                     "frac": round(value / world * gflop_my / 1e3 / 157.3, 4),
-                                    "bound": "VALU pipe: 69 % active per SIMD, ~88 % on the critical SIMD of the sub-step loop (DESIGN.md 4.1)"}
+                                    "bound": "VALU pipe: the four SIMDs of the sub-step loop are balanced to within 5 % (DESIGN.md 4.1)"}
         if roof is not None:
             out["roofline"] = roof
         if delivered is not None:
@@ -366,7 +366,7 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
     keep = ov[~slow]
     r, dt, ok = year_rate(len(keep), as_dicts(keep))
     out["config5_without_those_members"] = {"members": int(len(keep)), "member_years_per_s": round(r, 2), "finite": ok,
-                                            "bound": "VALU issue of the chain rows (pair kernel)"}
+                                            "bound": "workgroup throughput of the pair kernel: LDS staging not overlapped with arithmetic at 8 waves per CU"}
     # standalone diffusion sweep, HIP events on the launching stream
     batch = 1024
     n = batch * nx * ny
