@@ -21,7 +21,6 @@ namespace {
 
 constexpr int kPairNx = 384, kPairNq = 96, kPairP = 6;
 static_assert(kPairP == 6, "the chain's min3 reduction is written for six points per lane");
-constexpr int kSplitMinSweeps = 96; // a band's longest diffusion chain is split by tracer from this length on
 constexpr int kPHalf = 4 * kPairNq;  // floats per half-row
 constexpr int kPRow = 2 * kPHalf;    // floats per LDS row (768)
 
@@ -34,128 +33,12 @@ __device__ __forceinline__ q8 ld8g(const lfloat* row, int q) {
   r.v[0] = v2{a.x, a.y}; r.v[1] = v2{a.z, a.w}; r.v[2] = v2{b.x, b.y}; r.v[3] = v2{b.z, b.w};
   return r;
 }
-__device__ __forceinline__ v2 dpp_prev(v2 x) { return v2{wave_from_prev(x.x), wave_from_prev(x.y)}; }
-__device__ __forceinline__ v2 dpp_next(v2 x) { return v2{wave_from_next(x.x), wave_from_next(x.y)}; }
 
-// one iterating row, both tracers: time2 sweeps of the diffusion and of the advection stencil from the same start,
-// then the latitudinal terms and the update (src/greb.f90:651-719, :837-911, :585-590, :756-795, :721, :913, :549)
-__device__ void pair_chain_row(const lfloat* sT, const lfloat* sW, const lfloat* sU, const lfloat* sV, int r0, int k0,
-                               int k, int ny, const RowK& rk, int lane, float* __restrict__ out_row /* global [nx][2] */) {
-  constexpr int P = kPairP, W = P + 6;
-  const lfloat* Trow = sT + (k - r0) * kPRow;
-  const lfloat* Wrow = sW + (k - r0) * kPRow;
-  v2 T0[W], w[W];
-  // load by single points (ds_read_b64): 12 window points, periodic
-#pragma unroll
-  for (int i = 0; i < W; ++i) {
-    int x = P * lane - 3 + i;
-    x = x < 0 ? x + kPairNx : (x >= kPairNx ? x - kPairNx : x);
-    const int o = ppair_off(x >> 1) + (x & 1) * 2;
-    T0[i] = *(const __attribute__((address_space(3))) v2*)(Trow + o);
-    w[i] = *(const __attribute__((address_space(3))) v2*)(Wrow + o);
-  }
-  float us[P]; // zonal wind scaled by adv_ccx2/20 (staging), so the sign split is one max/min
-#pragma unroll
-  for (int i = 0; i < P; ++i) us[i] = sU[(k - k0) * kPairNx + P * lane + i];
-  const bool bug_lane = lane == 63; // its point P-3 is longitude xdim-2 (1-based), src/greb.f90:881
-  const int time2[2] = {__builtin_amdgcn_readfirstlane(rk.dif_time2), __builtin_amdgcn_readfirstlane(rk.adv_time2)};
-  if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(3); // greb_stencil.h: the long chains issue first
-  const float cs = rk.dif_cc * 0.05f;
-  v2 Th[2][P];
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    // The weights, the row constant and the (pre-scaled) wind do not change during the chain: the increment of
-    // point c is a fixed linear form in the six differences e[m] = T[m+1] - T[m] around it, per tracer -- the same
-    // coefficient form as the scalar any-grid kernel (greb_stencil.h: chain_lon_regs), on (Tair, q) pairs.
-    v2 K[P][6];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-      const int c = 3 + i;
-      if (which) { // -neg*(10 Pp[c] + 4 Pp[c+1] + Pp[c+2]) - pos*(10 Pm[c-1] + 4 Pm[c-2] + Pm[c-3]), :845-851
-        float pos, neg;
-        split_sign(us[i], pos, neg);
-        K[i][0] = -pos * w[c - 3]; K[i][1] = (-4.f * pos) * w[c - 2]; K[i][2] = (-10.f * pos) * w[c - 1];
-        K[i][3] = (-10.f * neg) * w[c + 1]; K[i][4] = (-4.f * neg) * w[c + 2]; K[i][5] = -neg * w[c + 3];
-        if (i == P - 3 && bug_lane) { K[i][4] = -neg * w[c + 3]; K[i][5] = -neg * w[c + 3]; } // :881
-      } else { // cs*(6(Pp[c] - Pm[c-1]) + 3(Pp[c+1] - Pm[c-2]) + (Pp[c+2] - Pm[c-3])), :595-600
-        K[i][0] = -cs * w[c - 3]; K[i][1] = (-3.f * cs) * w[c - 2]; K[i][2] = (-6.f * cs) * w[c - 1];
-        K[i][3] = (6.f * cs) * w[c + 1]; K[i][4] = (3.f * cs) * w[c + 2]; K[i][5] = cs * w[c + 3];
-      }
-    }
-    v2 T[W];
-#pragma unroll
-    for (int i = 0; i < W; ++i) T[i] = T0[i];
-    for (int tt = 0; tt < time2[which]; ++tt) {
-      if (tt > 0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          T[i] = dpp_prev(T[P + i]);
-          T[P + 3 + i] = dpp_next(T[3 + i]);
-        }
-      }
-      v2 e[W - 1];
-#pragma unroll
-      for (int m = 0; m < W - 1; ++m) e[m] = pk_sub(T[m + 1], T[m]);
-      v2 Tn[P], dv[P];
-#pragma unroll
-      for (int i = 0; i < P; ++i) {
-        v2 d = K[i][0] * e[i];
-#pragma unroll
-        for (int m = 1; m < 6; ++m) d = __builtin_elementwise_fma(K[i][m], e[i + m], d);
-        dv[i] = d;
-        Tn[i] = T[3 + i] + d;
-      }
-      float mn = min3f(Tn[0].x, Tn[0].y, Tn[1].x);
-      mn = min3f(mn, Tn[1].y, Tn[2].x); mn = min3f(mn, Tn[2].y, Tn[3].x); mn = min3f(mn, Tn[3].y, Tn[4].x);
-      mn = min3f(mn, Tn[4].y, Tn[5].x); mn = min3f(mn, Tn[5].y, Tn[5].y);
-      if (__builtin_expect(!(mn > 0.f), 0)) { // the clamp (:715 / :907), decided per component only where needed
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-          const int c = 3 + i;
-          v2 d = dv[i];
-          d.x = (d.x <= -T[c].x) ? -0.9f * T[c].x : d.x;
-          d.y = (d.y <= -T[c].y) ? -0.9f * T[c].y : d.y;
-          Tn[i] = T[c] + d;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < P; ++i) T[3 + i] = Tn[i];
-    }
-#pragma unroll
-    for (int i = 0; i < P; ++i) Th[which][i] = T[3 + i];
-  }
-  // latitudinal terms: rows k-2 .. k+2 at the own longitudes; rows outside the grid contribute nothing
-  if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
-  const float am = (k == 1) ? 3.f : 1.f, ap = (k == ny - 2) ? 3.f : 1.f; // :766-769, :784-787 (v is scaled by ccy/3)
-#pragma unroll
-  for (int i = 0; i < P; ++i) {
-    const int x = P * lane + i;
-    const int o = ppair_off(x >> 1) + (x & 1) * 2;
-    const v2 own = T0[3 + i];
-    auto rowv = [&](const lfloat* base, int kk) { return *(const __attribute__((address_space(3))) v2*)(base + (kk - r0) * kPRow + o); };
-    const v2 z = v2{0.f, 0.f};
-    const v2 Tm1 = k >= 1 ? rowv(sT, k - 1) : own, Tp1 = k <= ny - 2 ? rowv(sT, k + 1) : own;
-    const v2 Tm2 = k >= 2 ? rowv(sT, k - 2) : own, Tp2 = k <= ny - 3 ? rowv(sT, k + 2) : own;
-    const v2 Wm1 = k >= 1 ? rowv(sW, k - 1) : z, Wp1 = k <= ny - 2 ? rowv(sW, k + 1) : z;
-    const v2 Wm2 = k >= 2 ? rowv(sW, k - 2) : z, Wp2 = k <= ny - 3 ? rowv(sW, k + 2) : z;
-    float vpos, vneg;
-    split_sign(sV[(k - k0) * kPairNx + x], vpos, vneg);
-    const v2 gm1 = Wm1 * pk_sub(Tm1, own), gp1 = Wp1 * pk_sub(Tp1, own);
-    const v2 dm2 = Wm2 * pk_sub(own, Tm2), dp2 = Wp2 * pk_sub(own, Tp2);
-    const v2 ddy = rk.dif_ccy * (gm1 + gp1);
-    const v2 day = (ap * vneg) * (dp2 - gp1) - (am * vpos) * (dm2 - gm1);
-    const v2 dd = w[3 + i] * ((Th[0][i] - own) + ddy); // :718, :721
-    const v2 da = (Th[1][i] - own) + day;              // :910, :913
-    const v2 xn = (own + dd) + da;                     // :549
-    *(float2*)(out_row + 2 * x) = make_float2(xn.x, xn.y);
-  }
-}
-
-// ONE tracer (C = 0: Tair, 1: q) of an iterating row, scalar arithmetic: the longest chain of a latitude band is
-// taken by two waves, one per tracer.  A chain's latency is its instruction count (a lone wave issues one instruction
-// per ~5 cycles, packed or not) and the pair form's sweep is ~1.7x the scalar one's (both components' selects and
-// halo moves, packed instructions contending with whatever shares the SIMD): 225 sweeps take ~65 us as pairs and
-// ~38 us per tracer side by side.  Same coefficient form, same operation order per tracer as pair_chain_row.
+// ONE tracer (C = 0: Tair, 1: q) of an iterating row: the row's dif_time2 + adv_time2 dependent sweeps as scalar
+// chains in the registers of one wave (greb_chain6.h: 36 instructions per sweep; a chain's latency is its instruction
+// count, and per tracer the pipe time of a sweep is ~120 cycles where the same sweep on (Tair,q) pairs -- 11 packed
+// subtractions, 36 packed multiply-adds, 12 halo moves, 2 x 6 selects -- took ~450 for the two), then the latitudinal
+// terms and the update of that tracer.  Tair and q of a row are independent chains, so they are separate tasks.
 template <int C>
 __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lfloat* sU, const lfloat* sV, int r0, int k0,
                                     int k, int ny, const RowK& rk, int lane, float* __restrict__ out_row /* global [nx][2] */) {
@@ -226,66 +109,151 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lf
   }
 }
 
-__global__ __launch_bounds__(256) void sweep_pair_kernel(const float* __restrict__ X2, const float* __restrict__ W2p,
-                                                         const float* __restrict__ ug, const float* __restrict__ vg,
-                                                         float* __restrict__ Xnew2, const RowTables* __restrict__ tabp,
-                                                         const int* __restrict__ tab_index, int ny, int rows_per_band) {
+// Members per workgroup (256 threads each).  A band's weights (24 KB) and winds (12 KB) are the same for every member,
+// only its 24 KB of tracer rows are the member's own, and skip experiments (62 members: 57 us per launch, of which 26
+// with all arithmetic skipped) showed the launch co-limited by exactly that staging.  What paid: all global loads of a
+// band requested before anything is waited for (26 -> 19.6 us with the arithmetic skipped, 56.5 -> 52.6 us in all).
+// What did not: sharing the weights and winds among 2 members per workgroup (84 KB of LDS, one 8-wave workgroup per
+// CU: 56.0 us, and 49.1 instead of 36.0 at 40 members -- the phases of a workgroup are sequential, and one resident
+// workgroup has nobody to overlap them with); 3 or 4 members cap the kernel at 168 / 128 VGPRs where it wants 223
+// (spills: 76 / 186 us).  The code keeps the group size as a parameter.
+constexpr int kPairGroup = 1;
+constexpr int kMaxBandRows = 4; // (rows + 4) x 192 point pairs = kXIt x 256 tracer loads per thread
+constexpr int kPairThreads = 256 * kPairGroup;
+
+__global__ __launch_bounds__(kPairThreads) void sweep_pair_kernel(const float* __restrict__ X2, const float* __restrict__ W2p,
+                                                                  const float* __restrict__ ug, const float* __restrict__ vg,
+                                                                  float* __restrict__ Xnew2, const RowTables* __restrict__ tabp,
+                                                                  const int* __restrict__ tab_index, int ny, int n_members,
+                                                                  int rows_per_band, int nbands, int dbg) {
   extern __shared__ __align__(16) float lds_raw[];
   lfloat* lds = (lfloat*)lds_raw;
-  const int m = blockIdx.x;
-  const RowTables& tab = tabp[tab_index ? tab_index[m] : 0];
-  const int nbands = gridDim.y; // poles first: the polar bands carry the long chains
-  const int band = (blockIdx.y & 1) ? nbands - 1 - (blockIdx.y >> 1) : (blockIdx.y >> 1);
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255; // member slot of the workgroup, thread within the member
+  // Workgroup -> (member group, band), XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs, each with
+  // its own L2.  Neighbouring bands of a member share 4 of their 8 tracer rows, so all bands of a member group are
+  // given to ONE XCD (id % 8 = group % 8) and follow each other closely there: the second reader of a halo row finds
+  // it in that XCD's L2 instead of fetching it from the Infinity Cache again.  Poles first: the polar bands carry the
+  // long chains.
+  const int ngroups = (n_members + kPairGroup - 1) / kPairGroup, per_xcd = (ngroups + 7) / 8;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int group = (slot % per_xcd) * 8 + xcd, bo = slot / per_xcd;
+  if (group >= ngroups) return; // (whole workgroup)
+  const int band = (bo & 1) ? nbands - 1 - (bo >> 1) : (bo >> 1);
+  const int m = group * kPairGroup + grp;
+  const bool live = m < n_members; // (the last group may hold fewer members; its idle slots only join the barrier)
+  const RowTables& tab = tabp[tab_index ? tab_index[live ? m : n_members - 1] : 0];
   const int k0 = band * rows_per_band, k1 = min(ny, k0 + rows_per_band);
   const int r0 = max(0, k0 - 2), r1 = min(ny, k1 + 2), nrows = r1 - r0, nb = k1 - k0;
-  lfloat* sT = lds;
-  lfloat* sW = sT + nrows * kPRow;
-  lfloat* sU = sW + nrows * kPRow;
-  lfloat* sV = sU + nb * kPairNx;
-  lfloat* rowk = sV + nb * kPairNx;
-  stage_row_consts(rowk, tab, ny);
-  const size_t fo = (size_t)m * ny * kPairNx * 2;
+  // shared by the members: weights, winds; per member: tracer rows, row constants of the band's rows
+  lfloat* sW = lds;
+  lfloat* sU = sW + (rows_per_band + 4) * kPRow;
+  lfloat* sV = sU + rows_per_band * kPairNx;
+  lfloat* sT = sV + rows_per_band * kPairNx + grp * ((rows_per_band + 4) * kPRow + rows_per_band * kRowKWords);
+  lfloat* rowk_band = sT + (rows_per_band + 4) * kPRow;
+  const lfloat* rowk = rowk_band - k0 * kRowKWords; // indexed by the absolute row
+  const size_t fo = (size_t)(live ? m : 0) * ny * kPairNx * 2;
+  // Everything the band needs from global memory is requested before anything is waited for: the loads are
+  // unconditional (clamped indices) and only the LDS stores are predicated -- a load under a condition is preceded by
+  // s_waitcnt vmcnt(0), which turned the staging into six dependent round trips.
   // global rows are [nx][2] = one dwordx4 per point pair i; LDS rows are [half][quad][4]
-  for (int i = threadIdx.x; i < nrows * (kPairNx / 2); i += 256) {
-    const int r = i / (kPairNx / 2), pi = i % (kPairNx / 2);
-    const size_t g = ((size_t)(r0 + r) * kPairNx + 2 * pi) * 2;
-    st4(sT + r * kPRow + ppair_off(pi), ld4(X2 + fo + g));
-    st4(sW + r * kPRow + ppair_off(pi), ld4(W2p + g));
-  }
-  for (int i = threadIdx.x; i < nb * kPairNq; i += 256) { // winds, pre-scaled by the row's advection constants
-    const int k = k0 + i / kPairNq;
-    const float cu = tab.subcycled[k] ? tab.adv_ccx2[k] * 0.05f : tab.adv_ccx[k] * (1.f / 3.f);
-    const float cv = tab.adv_ccy * (1.f / 3.f);
-    f4 uq = ld4(ug + (size_t)k0 * kPairNx + 4 * i), vq = ld4(vg + (size_t)k0 * kPairNx + 4 * i);
+  constexpr int kXIt = 6; // tracer loads in flight per thread: (4 + 4 rows) x 192 point pairs / 256 threads
+  constexpr int kWIt = (kXIt + kPairGroup - 1) / kPairGroup;
+  constexpr int kUIt = (kMaxBandRows * kPairNq + kPairThreads - 1) / kPairThreads; // wind quads per thread
+  const int npair = nrows * (kPairNx / 2), nwind = nb * kPairNq;
+  auto goff = [&](int i) { return ((size_t)(r0 + i / (kPairNx / 2)) * kPairNx + 2 * (i % (kPairNx / 2))) * 2; };
+  auto loff = [&](int i) { return (i / (kPairNx / 2)) * kPRow + ppair_off(i % (kPairNx / 2)); };
+  for (int base = 0; base < npair; base += kXIt * 256) {
+    f4 x[kXIt], wq[kWIt], uq[kUIt], vq[kUIt];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { uq.v[e] *= cu; vq.v[e] *= cv; }
-    st4(sU + 4 * i, uq); st4(sV + 4 * i, vq);
+    for (int j = 0; j < kXIt; ++j) x[j] = ld4(X2 + fo + goff(min(base + j * 256 + tid, npair - 1)));
+#pragma unroll
+    for (int j = 0; j < kWIt; ++j) wq[j] = ld4(W2p + goff(min(base + j * kPairThreads + (int)threadIdx.x, npair - 1)));
+    float cu[kUIt], cv = 0.f;
+    float rc[kRowKWords] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (base == 0) { // winds and row constants ride in the first batch
+#pragma unroll
+      for (int j = 0; j < kUIt; ++j) {
+        const int iw = min(j * kPairThreads + (int)threadIdx.x, nwind - 1);
+        uq[j] = ld4(ug + (size_t)k0 * kPairNx + 4 * iw); vq[j] = ld4(vg + (size_t)k0 * kPairNx + 4 * iw);
+      }
+      // (the tables hang off tab_index[m]: a dependent round trip, which must not be waited for before the loads above
+      // are on their way)
+      __builtin_amdgcn_sched_barrier(0);
+      // pre-scaled by the row's advection constants (those do not depend on the member: only kappa is perturbed,
+      // src/greb.f90:752-753, 840)
+#pragma unroll
+      for (int j = 0; j < kUIt; ++j) {
+        const int kw = k0 + min(j * kPairThreads + (int)threadIdx.x, nwind - 1) / kPairNq;
+        const float c2 = tab.adv_ccx2[kw], c1 = tab.adv_ccx[kw];
+        cu[j] = tab.subcycled[kw] ? c2 * 0.05f : c1 * (1.f / 3.f);
+      }
+      cv = tab.adv_ccy * (1.f / 3.f);
+      const int k = k0 + min(tid, nb - 1), sub = tab.subcycled[k]; // the member's constants of the band's rows
+      const float d2 = tab.dif_ccx2[k], d1 = tab.dif_ccx[k], a2 = tab.adv_ccx2[k], a1 = tab.adv_ccx[k];
+      rc[0] = sub ? d2 : d1; rc[1] = sub ? a2 : a1; rc[2] = tab.dif_ccy; rc[3] = tab.adv_ccy;
+      rc[4] = __int_as_float(sub); rc[5] = __int_as_float(tab.dif_time2[k]); rc[6] = __int_as_float(tab.adv_time2[k]);
+    }
+#pragma unroll
+    for (int j = 0; j < kXIt; ++j) {
+      const int i = base + j * 256 + tid;
+      if (live && i < npair) st4(sT + loff(i), x[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kWIt; ++j) {
+      const int i = base + j * kPairThreads + (int)threadIdx.x;
+      if (i < min(npair, base + kXIt * 256)) st4(sW + loff(i), wq[j]);
+    }
+    if (base == 0) {
+#pragma unroll
+      for (int j = 0; j < kUIt; ++j) {
+        const int iw = j * kPairThreads + (int)threadIdx.x;
+        if (iw < nwind) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { uq[j].v[e] *= cu[j]; vq[j].v[e] *= cv; }
+          st4(sU + 4 * iw, uq[j]); st4(sV + 4 * iw, vq[j]);
+        }
+      }
+      if (tid < nb) {
+        st4(rowk_band + tid * kRowKWords, f4{{rc[0], rc[1], rc[2], rc[3]}});
+        st4(rowk_band + tid * kRowKWords + 4, f4{{rc[4], rc[5], rc[6], rc[7]}});
+      }
+    }
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // iterating rows.  The band's longest chain, if it is long enough to set the length of the launch, is split by
-  // tracer over waves 0 and 1 (scalar arithmetic); the other iterating rows go one wave each to the remaining waves.
-  int ksplit = -1, tmax = kSplitMinSweeps - 1;
-  for (int k = k0; k < k1; ++k) {
-    const int t = tab.dif_time2[k];
-    if (t > tmax) { tmax = t; ksplit = k; }
-  }
-  int ci = 0;
-  for (int k = k0; k < k1; ++k) {
-    const RowK rk = row_consts((const lfloat*)rowk, k);
-    if (!(rk.dif_time2 > 1 || rk.adv_time2 > 1)) continue;
-    float* orow = Xnew2 + fo + (size_t)k * kPairNx * 2;
-    if (k == ksplit) {
-      if (wave == 0) pair_chain_row_comp<0>(sT, sW, sU, sV, r0, k0, k, ny, rk, lane, orow);
-      if (wave == 1) pair_chain_row_comp<1>(sT, sW, sU, sV, r0, k0, k, ny, rk, lane, orow);
-    } else if (ksplit >= 0) {
-      if (2 + (ci++ & 1) == wave) pair_chain_row(sT, sW, sU, sV, r0, k0, k, ny, rk, lane, orow);
-    } else if ((ci++ & 3) == wave) {
-      pair_chain_row(sT, sW, sU, sV, r0, k0, k, ny, rk, lane, orow);
+  if (!live) return;
+  const int wave = tid >> 6, lane = tid & 63;
+  // iterating rows: every (row, tracer) is one chain task; longest row first, each task to the wave with the least
+  // chain work so far (the same scalar bookkeeping in all four waves).  In the polar bands that puts the two tracers of
+  // the 225-sweep row on two waves -- two SIMDs -- and everything else on the other two.
+  {
+    const int me = __builtin_amdgcn_readfirstlane(wave);
+    int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    unsigned done = 0;
+    for (int it = 0; it < nb && !(dbg & 1); ++it) {
+      int kb = -1, cb = 0;
+      for (int k = k0; k < k1; ++k) { // (from the staged constants: the tables themselves are a global round trip away)
+        const int td = __builtin_amdgcn_readfirstlane(__float_as_int(rowk[k * kRowKWords + 5]));
+        const int ta = __builtin_amdgcn_readfirstlane(__float_as_int(rowk[k * kRowKWords + 6]));
+        if (!((done >> (k - k0)) & 1u) && (td > 1 || ta > 1) && td + ta > cb) { cb = td + ta; kb = k; }
+      }
+      if (kb < 0) break;
+      done |= 1u << (kb - k0);
+      const RowK rk = row_consts((const lfloat*)rowk, kb);
+      float* orow = Xnew2 + fo + (size_t)kb * kPairNx * 2;
+#pragma unroll
+      for (int C = 0; C < 2; ++C) {
+        const int m01 = l1 < l0 ? 1 : 0, v01 = l1 < l0 ? l1 : l0, m23 = l3 < l2 ? 3 : 2, v23 = l3 < l2 ? l3 : l2;
+        const int to = v23 < v01 ? m23 : m01;
+        l0 += to == 0 ? cb : 0; l1 += to == 1 ? cb : 0; l2 += to == 2 ? cb : 0; l3 += to == 3 ? cb : 0;
+        if (to == me) {
+          if (C == 0) pair_chain_row_comp<0>(sT, sW, sU, sV, r0, k0, kb, ny, rk, lane, orow);
+          else pair_chain_row_comp<1>(sT, sW, sU, sV, r0, k0, kb, ny, rk, lane, orow);
+        }
+      }
     }
   }
   // single-sweep rows: pair-quads, all threads
-  for (int i = threadIdx.x; i < nb * kPairNq; i += 256) {
+  for (int i = tid; i < nb * kPairNq && !(dbg & 2); i += 256) {
     const int k = k0 + i / kPairNq, q = i % kPairNq;
     const RowK rk = row_consts((const lfloat*)rowk, k);
     if (rk.dif_time2 > 1 || rk.adv_time2 > 1) continue;
@@ -335,23 +303,28 @@ __global__ void pack_pairs_kernel(const float* __restrict__ state, float* __rest
 
 bool pair_sweep_supported(int nx, int ny) { return nx == kPairNx && ny >= 5 && ny <= kMaxNy; }
 
-// rows per band: (rows+4) x 2 arrays x 3 KB + rows x 3 KB of winds + 6 KB of row constants; 4 rows = 67 KB, two workgroups per CU
+// rows per band; LDS = weights (rows+4) x 3 KB + winds rows x 3 KB + per member ((rows+4) x 3 KB + row constants):
+// 4 rows, 4 members: 24 + 12 + 4 x 24 = 133 KB, one 16-wave workgroup per CU
 static int pair_band_rows() {
   static const int r = tuning_int("GREB_PAIR_ROWS", 4); // -DGREB_TUNING builds only
   return r;
 }
 static size_t pair_lds_bytes(int rows) {
-  return (size_t)(((rows + 4) * 2 * kPRow) + 2 * rows * kPairNx + kMaxNy * kRowKWords) * sizeof(float);
+  return (size_t)((rows + 4) * kPRow + 2 * rows * kPairNx + kPairGroup * ((rows + 4) * kPRow + rows * kRowKWords)) * sizeof(float);
 }
 
 hipError_t launch_substep_pairs(const float* X2, const float* W2p, const float* u, const float* v, float* Xnew2,
                                 const RowTables* tabs, const int* tab_index, int ny, int n_members, hipStream_t s) {
   const int rows = pair_band_rows(), bands = (ny + rows - 1) / rows;
+  if (rows < 1 || rows > kMaxBandRows) return hipErrorInvalidValue;
   const size_t lds = pair_lds_bytes(rows);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_pair_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(sweep_pair_kernel, dim3(n_members, bands), dim3(256), lds, s, X2, W2p, u, v, Xnew2, tabs, tab_index, ny, rows);
+  const int ngroups = (n_members + kPairGroup - 1) / kPairGroup;
+  hipLaunchKernelGGL(sweep_pair_kernel, dim3(8 * ((ngroups + 7) / 8) * bands), dim3(kPairThreads), lds, s, X2, W2p, u, v, Xnew2, tabs,
+                     tab_index, ny, n_members, rows, bands,
+                     tuning_int("GREB_DEBUG_PAIR", 0)); // -DGREB_TUNING builds only: bit 0 skips the chains, bit 1 the single-sweep rows
   return hipGetLastError();
 }
 
