@@ -49,20 +49,50 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
   lfloat* sV = sU + (kWinds ? (k1 - k0) * nx : 0);
   lfloat* scratch = sV + (kWinds ? (k1 - k0) * nx : 0); // [nwaves][4*nx]
   lfloat* rowk = scratch + 4 * 4 * nx;                              // [ny][kRowKWords]
-  stage_row_consts(rowk, tab, ny);
   const size_t fo = (size_t)b * nx * ny;
   const size_t fw = (size_t)(wmod ? b % wmod : b) * nx * ny;
   const size_t fu = uv_shared ? 0 : fo;
-  for (int i = threadIdx.x; i < nrows * nq; i += blockDim.x) {
-    st4(sT + 4 * i, ld4(T1 + fo + (size_t)r0 * nx + 4 * i));
-    st4(sW + 4 * i, ld4(wz + fw + (size_t)r0 * nx + 4 * i));
-  }
-  if (kWinds)
-    for (int i = threadIdx.x; i < (k1 - k0) * nq; i += blockDim.x) {
-      const bool calm = calm_odd && (b & 1);
-      st4(sU + 4 * i, calm ? zero4() : ld4(ug + fu + (size_t)k0 * nx + 4 * i));
-      st4(sV + 4 * i, calm ? zero4() : ld4(vg + fu + (size_t)k0 * nx + 4 * i));
+  // Staging.  Everything the band needs from global memory is requested before anything is waited for: unconditional
+  // loads (clamped indices) in batches of kIt per thread, only the LDS stores predicated.  (Written as a plain
+  // `for (...) st4(lds, ld4(global))` loop this was one dependent round trip per iteration, and a load under a condition
+  // is preceded by s_waitcnt vmcnt(0): six to seven round trips ahead of the 225-sweep chain that sets the length of the
+  // 384x192 launch.)  The row tables hang off tab_index[]: they are requested after the first batch is on its way.
+  constexpr int kIt = 4;
+  const int nT = nrows * nq, nU = kWinds ? (k1 - k0) * nq : 0, bd = blockDim.x, tid = threadIdx.x;
+  const bool calm = calm_odd && (b & 1);
+  for (int base = 0; base < max(nT, nU); base += kIt * bd) {
+    f4 a[kIt], w[kIt], uq[kIt], vq[kIt];
+#pragma unroll
+    for (int j = 0; j < kIt; ++j) {
+      const int i = min(base + j * bd + tid, nT - 1);
+      a[j] = ld4(T1 + fo + (size_t)r0 * nx + 4 * i);
+      w[j] = ld4(wz + fw + (size_t)r0 * nx + 4 * i);
     }
+    if (kWinds && base < nU) {
+#pragma unroll
+      for (int j = 0; j < kIt; ++j) {
+        const int i = min(base + j * bd + tid, nU - 1);
+        uq[j] = ld4(ug + fu + (size_t)k0 * nx + 4 * i);
+        vq[j] = ld4(vg + fu + (size_t)k0 * nx + 4 * i);
+      }
+    }
+    if (base == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      stage_row_consts(rowk, tab, ny);
+    }
+#pragma unroll
+    for (int j = 0; j < kIt; ++j) {
+      const int i = base + j * bd + tid;
+      if (i < nT) { st4(sT + 4 * i, a[j]); st4(sW + 4 * i, w[j]); }
+    }
+    if (kWinds && base < nU) {
+#pragma unroll
+      for (int j = 0; j < kIt; ++j) {
+        const int i = base + j * bd + tid;
+        if (i < nU) { st4(sU + 4 * i, calm ? zero4() : uq[j]); st4(sV + 4 * i, calm ? zero4() : vq[j]); }
+      }
+    }
+  }
   __syncthreads();
   const Rows X{sT, r0, nx}, W{sW, r0, nx}, U{sU, k0, nx}, V{sV, k0, nx};
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
