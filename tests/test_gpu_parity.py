@@ -90,6 +90,12 @@ def test_stencil_edge_cases_strict(eng_mod, params, inputs, oracle_lib):
         df = eng_mod.diffusion(X, W, params)
         dr = o.diffusion(X, W)
         assert np.abs(df.astype(np.float64) - dr).max() <= 4e-6 * max(np.abs(dr).max(), 1e-30) + np.spacing(np.abs(X).max())
+        # ... and so must the fused engine's FAST circulation, whose polar rows are the four-chains-in-one-wave form
+        # (greb_member.hip: quad_chain_substep) with the clamp decided by the min test of greb_chain6.h: 24 sub-steps
+        cf = eng_mod.circulation(X, W, U, V, params)
+        cr = o.circulation(X, W, u=U, v=V)
+        err = np.abs(cf.astype(np.float64) - cr)
+        assert err.max() <= 1e-5 * max(np.abs(cr).max(), 1e-30) + 24 * np.spacing(np.abs(X).max()), err.max()
     o.close()
 
 
