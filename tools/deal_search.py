@@ -18,12 +18,13 @@ VARDIR = os.path.join(ROOT, "greb_climate_model_amd", "variants")
 
 DEALS = {
     "c":     "S0+F0 S2+H  T2+F1+F2 S1 T0 T1+F3 F4",
-    "c2":    "S0+F0 S2+H  T2+F1    S1 T0 T1+F3 F2+F4",
-    "c6":    "S0+F0 S2+F1 T2+H+F2  S1 T0 T1+F3 F4",
-    "c7":    "S0+H  S2+F0 T2+F1+F2 S1 T0 T1+F3 F4",
-    "c8":    "S0+F0 S2+H  T2+F1+F2 S1 T1+F3 T0 F4",
-    "c9":    "S0+F0 S2+H  T1+F1+F2 S1 T0 T2+F3 F4",
-    "c10":   "S0+F0 S1+H  T2+F1+F2 S2 T0 T1+F3 F4",
+    "d1":    "S0+F0 S2+H  T2+T1    S1 T0 F1+F3+F4 F2",
+    "d2":    "S0+F0 S2+H  T2+T1    S1 T0 F1+F2+F3 F4",
+    "d3":    "S0+F0 S2+H  T2+T1    S1 T0 F1+F2 F3+F4",
+    "d4":    "S0+F0 S2+H  T2+F1+F2 S1 T0 F3+F4 T1",
+    "d5":    "S0+F0 S2+F1 T2+T1    S1 T0 H+F2+F3 F4",
+    "d6":    "S0+F0 S2+T0 T2+F1    S1 H+F2 T1+F3 F4",
+    "d7":    "S0+F0 S2+H  T2+F1+F2 S1+F4 T0 T1+F3 -",
 }
 
 
