@@ -63,37 +63,37 @@ namespace greb {
 #define GREB_C6_SUB2 " neg_lo:[0,1] neg_hi:[0,1]\n"
 
 // one sweep: points in set I, result in set O, neighbour flavour F
-#define GREB_C6_SWEEP(I, O, F)                                                                                           \
-  "v_pk_add_f32 v[78:79], " GREB_C6_##I##1 ", " GREB_C6_##I##0 GREB_C6_SUB2            /* E3 = (e3, e6) */            \
-  "v_pk_add_f32 v[80:81], " GREB_C6_##I##2 ", " GREB_C6_##I##1 GREB_C6_SUB2            /* E4 = (e4, e7) */            \
-  "v_sub_f32 v82, " GREB_C6_##I##0H ", " GREB_C6_##I##2L "\n"                          /* e5 = o3 - o2 */             \
-  "v_sub_f32 v77, " GREB_C6_##I##0H ", " GREB_C6_##I##2L "\n"                          /* e5 again, as E2.hi */       \
-  "v_subrev_f32_dpp v76, " GREB_C6_##I##2H ", " GREB_C6_##I##0L GREB_C6_PREV_##F         /* e2 = o0 - prev o5 */        \
-  "v_sub_f32_dpp v83, " GREB_C6_##I##0L ", " GREB_C6_##I##2H GREB_C6_NEXT_##F            /* e8 = next o0 - o5 */        \
-  "v_mul_f32_dpp v84, v79, %[k00]" GREB_C6_PREV_##F                                         /* d0  = K00 * prev e6 */      \
-  "v_mul_f32 v85, %[k30], v78\n"                                                          /* d3  = K30 * e3 */           \
-  "v_mul_f32_dpp v86, v81, %[k10]" GREB_C6_PREV_##F                                         /* d1  = K10 * prev e7 */      \
-  "v_mul_f32 v87, %[k40], v80\n"                                                          /* d4  = K40 * e4 */           \
-  "v_pk_mul_f32 v[88:89], %[p20], v[76:77]\n"                                      /* (d2,d5)  = m0 * (e2,e5) */  \
-  "v_fmac_f32_dpp v84, v81, %[k01]" GREB_C6_PREV_##F                                        /* d0 += K01 * prev e7 */      \
-  "v_fmac_f32 v85, %[k31], v80\n"                                                         /* d3 += K31 * e4 */           \
-  "v_pk_fma_f32 v[86:87], %[p11], v[76:77], v[86:87]\n"                            /* (d1,d4) += m1 * (e2,e5) */  \
-  "v_pk_fma_f32 v[88:89], %[p21], v[78:79], v[88:89]\n"                            /* (d2,d5) += m1 * (e3,e6) */  \
-  "v_pk_fma_f32 v[84:85], %[p02], v[76:77], v[84:85]\n"                            /* (d0,d3) += m2 * (e2,e5) */  \
-  "v_pk_fma_f32 v[86:87], %[p12], v[78:79], v[86:87]\n"                            /* (d1,d4) += m2 * (e3,e6) */  \
-  "v_pk_fma_f32 v[88:89], %[p22], v[80:81], v[88:89]\n"                            /* (d2,d5) += m2 * (e4,e7) */  \
-  "v_pk_fma_f32 v[84:85], %[p03], v[78:79], v[84:85]\n"                            /* (d0,d3) += m3 * (e3,e6) */  \
-  "v_pk_fma_f32 v[86:87], %[p13], v[80:81], v[86:87]\n"                            /* (d1,d4) += m3 * (e4,e7) */  \
-  "v_pk_fma_f32 v[88:89], %[p23], v[82:83], v[88:89]\n"                            /* (d2,d5) += m3 * (e5,e8) */  \
-  "v_pk_fma_f32 v[84:85], %[p04], v[80:81], v[84:85]\n"                            /* (d0,d3) += m4 * (e4,e7) */  \
-  "v_pk_fma_f32 v[86:87], %[p14], v[82:83], v[86:87]\n"                            /* (d1,d4) += m4 * (e5,e8) */  \
-  "v_fmac_f32 v88, %[k24], v79\n"                                                         /* d2 += K24 * e6 */           \
-  "v_fmac_f32_dpp v89, v78, %[k54]" GREB_C6_NEXT_##F                                       /* d5 += K54 * next e3 */      \
-  "v_pk_fma_f32 v[84:85], %[p05], v[82:83], v[84:85]\n"                            /* (d0,d3) += m5 * (e5,e8) */  \
-  "v_fmac_f32 v86, %[k15], v79\n"                                                         /* d1 += K15 * e6 */           \
-  "v_fmac_f32_dpp v87, v78, %[k45]" GREB_C6_NEXT_##F                                        /* d4 += K45 * next e3 */      \
-  "v_fmac_f32 v88, %[k25], v81\n"                                                        /* d2 += K25 * e7 */           \
-  "v_fmac_f32_dpp v89, v80, %[k55]" GREB_C6_NEXT_##F                                       /* d5 += K55 * next e4 */      \
+#define GREB_C6_SWEEP(I, O, F)                                                                                        \
+  "v_pk_add_f32 v[78:79], " GREB_C6_##I##1 ", " GREB_C6_##I##0 GREB_C6_SUB2  /* E3 = (e3, e6) */                      \
+  "v_pk_add_f32 v[80:81], " GREB_C6_##I##2 ", " GREB_C6_##I##1 GREB_C6_SUB2  /* E4 = (e4, e7) */                      \
+  "v_sub_f32 v82, " GREB_C6_##I##0H ", " GREB_C6_##I##2L "\n"  /* e5 = o3 - o2 */                                     \
+  "v_sub_f32 v77, " GREB_C6_##I##0H ", " GREB_C6_##I##2L "\n"  /* e5 again, as E2.hi */                               \
+  "v_subrev_f32_dpp v76, " GREB_C6_##I##2H ", " GREB_C6_##I##0L GREB_C6_PREV_##F  /* e2 = o0 - prev o5 */             \
+  "v_sub_f32_dpp v83, " GREB_C6_##I##0L ", " GREB_C6_##I##2H GREB_C6_NEXT_##F  /* e8 = next o0 - o5 */                \
+  "v_mul_f32_dpp v84, v79, %[k00]" GREB_C6_PREV_##F  /* d0  = K00 * prev e6 */                                        \
+  "v_mul_f32 v85, %[k30], v78\n"  /* d3  = K30 * e3 */                                                                \
+  "v_mul_f32_dpp v86, v81, %[k10]" GREB_C6_PREV_##F  /* d1  = K10 * prev e7 */                                        \
+  "v_mul_f32 v87, %[k40], v80\n"  /* d4  = K40 * e4 */                                                                \
+  "v_pk_mul_f32 v[88:89], %[p20], v[76:77]\n"  /* (d2,d5)  = m0 * (e2,e5) */                                          \
+  "v_fmac_f32_dpp v84, v81, %[k01]" GREB_C6_PREV_##F  /* d0 += K01 * prev e7 */                                       \
+  "v_fmac_f32 v85, %[k31], v80\n"  /* d3 += K31 * e4 */                                                               \
+  "v_pk_fma_f32 v[86:87], %[p11], v[76:77], v[86:87]\n"  /* (d1,d4) += m1 * (e2,e5) */                                \
+  "v_pk_fma_f32 v[88:89], %[p21], v[78:79], v[88:89]\n"  /* (d2,d5) += m1 * (e3,e6) */                                \
+  "v_pk_fma_f32 v[84:85], %[p02], v[76:77], v[84:85]\n"  /* (d0,d3) += m2 * (e2,e5) */                                \
+  "v_pk_fma_f32 v[86:87], %[p12], v[78:79], v[86:87]\n"  /* (d1,d4) += m2 * (e3,e6) */                                \
+  "v_pk_fma_f32 v[88:89], %[p22], v[80:81], v[88:89]\n"  /* (d2,d5) += m2 * (e4,e7) */                                \
+  "v_pk_fma_f32 v[84:85], %[p03], v[78:79], v[84:85]\n"  /* (d0,d3) += m3 * (e3,e6) */                                \
+  "v_pk_fma_f32 v[86:87], %[p13], v[80:81], v[86:87]\n"  /* (d1,d4) += m3 * (e4,e7) */                                \
+  "v_pk_fma_f32 v[88:89], %[p23], v[82:83], v[88:89]\n"  /* (d2,d5) += m3 * (e5,e8) */                                \
+  "v_pk_fma_f32 v[84:85], %[p04], v[80:81], v[84:85]\n"  /* (d0,d3) += m4 * (e4,e7) */                                \
+  "v_pk_fma_f32 v[86:87], %[p14], v[82:83], v[86:87]\n"  /* (d1,d4) += m4 * (e5,e8) */                                \
+  "v_fmac_f32 v88, %[k24], v79\n"  /* d2 += K24 * e6 */                                                               \
+  "v_fmac_f32_dpp v89, v78, %[k54]" GREB_C6_NEXT_##F  /* d5 += K54 * next e3 */                                       \
+  "v_pk_fma_f32 v[84:85], %[p05], v[82:83], v[84:85]\n"  /* (d0,d3) += m5 * (e5,e8) */                                \
+  "v_fmac_f32 v86, %[k15], v79\n"  /* d1 += K15 * e6 */                                                               \
+  "v_fmac_f32_dpp v87, v78, %[k45]" GREB_C6_NEXT_##F  /* d4 += K45 * next e3 */                                       \
+  "v_fmac_f32 v88, %[k25], v81\n"  /* d2 += K25 * e7 */                                                               \
+  "v_fmac_f32_dpp v89, v80, %[k55]" GREB_C6_NEXT_##F  /* d5 += K55 * next e4 */                                       \
   "v_pk_add_f32 " GREB_C6_##O##0 ", " GREB_C6_##I##0 ", v[84:85]\n"                                                   \
   "v_pk_add_f32 " GREB_C6_##O##1 ", " GREB_C6_##I##1 ", v[86:87]\n"                                                   \
   "v_pk_add_f32 " GREB_C6_##O##2 ", " GREB_C6_##I##2 ", v[88:89]\n"                                                   \
@@ -148,13 +148,13 @@ __device__ __forceinline__ float chain_k(const ChainK& c) {
     return c.s[slot + hi];
   }
 }
-#define GREB_C6_K_OPERANDS(c)                                                                                          \
-  [k00] "v"(c.s[0]), [k30] "v"(c.s[1]), [k01] "v"(c.s[2]), [k31] "v"(c.s[3]), [k10] "v"(c.s[4]), [k40] "v"(c.s[5]),    \
-      [k15] "v"(c.s[6]), [k45] "v"(c.s[7]), [k24] "v"(c.s[8]), [k54] "v"(c.s[9]), [k25] "v"(c.s[10]),                  \
-      [k55] "v"(c.s[11]), [p02] "v"(c.p[0]), [p03] "v"(c.p[1]), [p04] "v"(c.p[2]), [p05] "v"(c.p[3]),                  \
-      [p11] "v"(c.p[4]), [p12] "v"(c.p[5]), [p13] "v"(c.p[6]), [p14] "v"(c.p[7]), [p20] "v"(c.p[8]),                   \
+#define GREB_C6_K_OPERANDS(c)                                                                                         \
+  [k00] "v"(c.s[0]), [k30] "v"(c.s[1]), [k01] "v"(c.s[2]), [k31] "v"(c.s[3]), [k10] "v"(c.s[4]), [k40] "v"(c.s[5]),   \
+      [k15] "v"(c.s[6]), [k45] "v"(c.s[7]), [k24] "v"(c.s[8]), [k54] "v"(c.s[9]), [k25] "v"(c.s[10]),                 \
+      [k55] "v"(c.s[11]), [p02] "v"(c.p[0]), [p03] "v"(c.p[1]), [p04] "v"(c.p[2]), [p05] "v"(c.p[3]),                 \
+      [p11] "v"(c.p[4]), [p12] "v"(c.p[5]), [p13] "v"(c.p[6]), [p14] "v"(c.p[7]), [p20] "v"(c.p[8]),                  \
       [p21] "v"(c.p[9]), [p22] "v"(c.p[10]), [p23] "v"(c.p[11])
-#define GREB_C6_CLOBBERS                                                                                                \
+#define GREB_C6_CLOBBERS                                                                                              \
   "vcc", "scc", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", \
       "v85", "v86", "v87", "v88", "v89", "v90"
 
@@ -163,35 +163,35 @@ __device__ __forceinline__ float chain_k(const ChainK& c) {
 // C++ the compiler copies the six points into and out of the fixed registers around every sweep (12 v_mov each).
 // It stops BEFORE a sweep whose result would need the clamp (min of the updated values <= 0, or NaN), with T holding
 // the last state that did not.
-#define GREB_C6_B_TO_A                                                                                                 \
-  "v_mov_b64 v[64:65], v[70:71]\n"                                                                                     \
-  "v_mov_b64 v[66:67], v[72:73]\n"                                                                                     \
+#define GREB_C6_B_TO_A                                                                                                \
+  "v_mov_b64 v[64:65], v[70:71]\n"                                                                                    \
+  "v_mov_b64 v[66:67], v[72:73]\n"                                                                                    \
   "v_mov_b64 v[68:69], v[74:75]\n"
-#define GREB_C6_LOOP(F)                                                                                                \
-  "s_cmp_lt_i32 %[rem], 2\n"                                                                                           \
-  "s_cbranch_scc1 4f\n"                                                                                                \
-  "1:\n" GREB_C6_SWEEP(A, B, F)                                                                                        \
-  "v_cmp_nlt_f32 vcc, 0, v90\n"                                                                                        \
-  "s_cbranch_vccnz 3f\n" GREB_C6_SWEEP(B, A, F)                                                                        \
-  "v_cmp_nlt_f32 vcc, 0, v90\n"                                                                                        \
-  "s_cbranch_vccnz 2f\n"                                                                                               \
-  "s_sub_i32 %[rem], %[rem], 2\n"                                                                                      \
-  "s_cmp_ge_i32 %[rem], 2\n"                                                                                           \
-  "s_cbranch_scc1 1b\n"                                                                                                \
-  "s_branch 4f\n"                                                                                                      \
-  "2:\n" /* the second sweep of the trip needs the clamp: keep the first */                                            \
-  GREB_C6_B_TO_A                                                                                                       \
-  "s_sub_i32 %[rem], %[rem], 1\n"                                                                                      \
-  "s_branch 3f\n"                                                                                                      \
-  "4:\n" /* none or one left */                                                                                        \
-  "s_cmp_lt_i32 %[rem], 1\n"                                                                                           \
-  "s_cbranch_scc1 3f\n" GREB_C6_SWEEP(A, B, F)                                                                         \
-  "v_cmp_nlt_f32 vcc, 0, v90\n"                                                                                        \
-  "s_cbranch_vccnz 3f\n"                                                                                               \
-  GREB_C6_B_TO_A                                                                                                       \
-  "s_mov_b32 %[rem], 0\n"                                                                                              \
+#define GREB_C6_LOOP(F)                                                                                               \
+  "s_cmp_lt_i32 %[rem], 2\n"                                                                                          \
+  "s_cbranch_scc1 4f\n"                                                                                               \
+  "1:\n" GREB_C6_SWEEP(A, B, F)                                                                                       \
+  "v_cmp_nlt_f32 vcc, 0, v90\n"                                                                                       \
+  "s_cbranch_vccnz 3f\n" GREB_C6_SWEEP(B, A, F)                                                                       \
+  "v_cmp_nlt_f32 vcc, 0, v90\n"                                                                                       \
+  "s_cbranch_vccnz 2f\n"                                                                                              \
+  "s_sub_i32 %[rem], %[rem], 2\n"                                                                                     \
+  "s_cmp_ge_i32 %[rem], 2\n"                                                                                          \
+  "s_cbranch_scc1 1b\n"                                                                                               \
+  "s_branch 4f\n"                                                                                                     \
+  "2:\n" /* the second sweep of the trip needs the clamp: keep the first */                                           \
+  GREB_C6_B_TO_A                                                                                                      \
+  "s_sub_i32 %[rem], %[rem], 1\n"                                                                                     \
+  "s_branch 3f\n"                                                                                                     \
+  "4:\n" /* none or one left */                                                                                       \
+  "s_cmp_lt_i32 %[rem], 1\n"                                                                                          \
+  "s_cbranch_scc1 3f\n" GREB_C6_SWEEP(A, B, F)                                                                        \
+  "v_cmp_nlt_f32 vcc, 0, v90\n"                                                                                       \
+  "s_cbranch_vccnz 3f\n"                                                                                              \
+  GREB_C6_B_TO_A                                                                                                      \
+  "s_mov_b32 %[rem], 0\n"                                                                                             \
   "3:\n"
-#define GREB_C6_T_OPERANDS(T)                                                                                          \
+#define GREB_C6_T_OPERANDS(T)                                                                                         \
   "+{v64}"(T[0]), "+{v65}"(T[3]), "+{v66}"(T[1]), "+{v67}"(T[4]), "+{v68}"(T[2]), "+{v69}"(T[5])
 template <bool ROW16>
 __device__ __forceinline__ int chain_sweeps6(float (&T)[6], const ChainK& c, int rem /* wave-uniform */) {
