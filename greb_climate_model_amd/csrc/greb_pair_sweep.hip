@@ -1,15 +1,16 @@
-// greb_pair_sweep.hip -- FAST circulation sub-step of the any-grid engine on (Tair, q) PAIRS (384-wide grids).
+// greb_pair_sweep.hip -- FAST circulation sub-step of the any-grid engine for many members on 384-wide grids.
 //
 // The scalar any-grid kernel (greb_kernels.hip: sweep_kernel) treats the two transported tracers of a member as two
-// batch items.  At 384x192 every row is sub-cycled and the rows within ~18 degrees of the poles iterate (up to 225
-// Jacobi sweeps per diffusion call), so the launch is instruction-bound on those chains.  Both tracers see the same
-// winds, row constants and sweep counts: carrying them as v2 pairs makes every arithmetic instruction a packed
-// v_pk_*_f32 (greb_pair.h, as in the fused 96x48 engine) -- one chain, one address stream, one wind sign split for
-// the two of them.
+// batch items.  Here they travel as (Tair, q) PAIRS:
 //   X2 / Xnew2 : [member][ny][nx][{Tair,q}]   W2p : [ny][nx][{wz_air,wz_vapor}]   winds: [ny][nx], shared
-// One workgroup = one member x one latitude band.  LDS rows are [half][quad][4] (greb_pair.h) so the dwordx4
-// reads of neighbouring lanes do not collide.  Iterating rows live in registers: lane l owns longitudes 6l..6l+5,
-// halos by v_mov_b32_dpp wave_ror/rol:1 (the rotate is the periodic boundary).
+// One workgroup = one member x one latitude band, tracer rows and weights staged in LDS as [half][quad][4] rows
+// (greb_pair.h) so the dwordx4 reads of neighbouring lanes do not collide.
+//   * Single-sweep rows (most of the grid): pair-quads, every arithmetic instruction a packed v_pk_*_f32 on a
+//     (Tair,q) register pair (greb_pair.h, as in the fused 96x48 engine) -- one address stream, one wind sign split
+//     for the two tracers.
+//   * Iterating rows (within ~18 degrees of the poles, up to 225 Jacobi sweeps per diffusion call): one task per
+//     (row, tracer) in the registers of one wave, lane l owning longitudes 6l..6l+5 (greb_chain6.h: a chain's latency
+//     is its instruction count, and the two tracers are independent chains).
 #include <cstdlib>
 
 #include "greb_kernels.h"
@@ -40,7 +41,7 @@ __device__ __forceinline__ q8 ld8g(const lfloat* row, int q) {
 // subtractions, 36 packed multiply-adds, 12 halo moves, 2 x 6 selects -- took ~450 for the two), then the latitudinal
 // terms and the update of that tracer.  Tair and q of a row are independent chains, so they are separate tasks.
 template <int C>
-__device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lfloat* sU, const lfloat* sV, int r0, int k0,
+__device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const float* __restrict__ ug, const float* __restrict__ vg, int r0,
                                     int k, int ny, const RowK& rk, int lane, float* __restrict__ out_row /* global [nx][2] */) {
   constexpr int P = kPairP, W = P + 6;
   auto comp = [](v2 a) { return C == 0 ? a.x : a.y; };
@@ -55,9 +56,14 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lf
     T0[i] = Trow[o];
     w[i] = Wrow[o];
   }
-  float us[P];
+  // the row's winds, scaled by its advection constants (read once per task: nothing to gain from staging them)
+  const float cu = rk.sub ? rk.adv_cc * 0.05f : rk.adv_cc * (1.f / 3.f), cv = rk.adv_ccy * (1.f / 3.f);
+  float us[P], vs[P];
 #pragma unroll
-  for (int i = 0; i < P; ++i) us[i] = sU[(k - k0) * kPairNx + P * lane + i];
+  for (int i = 0; i < P; i += 2) {
+    const float2 a = *(const float2*)(ug + (size_t)k * kPairNx + P * lane + i), b = *(const float2*)(vg + (size_t)k * kPairNx + P * lane + i);
+    us[i] = cu * a.x; us[i + 1] = cu * a.y; vs[i] = cv * b.x; vs[i + 1] = cv * b.y;
+  }
   const bool bug_lane = lane == 63; // :881
   const int time2[2] = {__builtin_amdgcn_readfirstlane(rk.dif_time2), __builtin_amdgcn_readfirstlane(rk.adv_time2)};
   if (time2[0] >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(3); // greb_stencil.h: the long chains issue first
@@ -98,7 +104,7 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lf
     const float Wm1 = k >= 1 ? rowv(sW, k - 1) : 0.f, Wp1 = k <= ny - 2 ? rowv(sW, k + 1) : 0.f;
     const float Wm2 = k >= 2 ? rowv(sW, k - 2) : 0.f, Wp2 = k <= ny - 3 ? rowv(sW, k + 2) : 0.f;
     float vpos, vneg;
-    split_sign(sV[(k - k0) * kPairNx + x], vpos, vneg);
+    split_sign(vs[i], vpos, vneg);
     const float gm1 = Wm1 * (Tm1 - own), gp1 = Wp1 * (Tp1 - own);
     const float dm2 = Wm2 * (own - Tm2), dp2 = Wp2 * (own - Tp2);
     const float ddy = rk.dif_ccy * (gm1 + gp1);
@@ -109,7 +115,7 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const lf
   }
 }
 
-// Members per workgroup (256 threads each).  A band's weights (24 KB) and winds (12 KB) are the same for every member,
+// Members per workgroup (256 threads each).  A band's weights (24 KB) are the same for every member (so were its winds, 12 KB, staged then),
 // only its 24 KB of tracer rows are the member's own, and skip experiments (62 members: 57 us per launch, of which 26
 // with all arithmetic skipped) showed the launch co-limited by exactly that staging.  What paid: all global loads of a
 // band requested before anything is waited for (26 -> 19.6 us with the arithmetic skipped, 56.5 -> 52.6 us in all).
@@ -144,11 +150,9 @@ __global__ __launch_bounds__(kPairThreads) void sweep_pair_kernel(const float* _
   const RowTables& tab = tabp[tab_index ? tab_index[live ? m : n_members - 1] : 0];
   const int k0 = band * rows_per_band, k1 = min(ny, k0 + rows_per_band);
   const int r0 = max(0, k0 - 2), r1 = min(ny, k1 + 2), nrows = r1 - r0, nb = k1 - k0;
-  // shared by the members: weights, winds; per member: tracer rows, row constants of the band's rows
+  // shared by the members: weights; per member: tracer rows, row constants of the band's rows
   lfloat* sW = lds;
-  lfloat* sU = sW + (rows_per_band + 4) * kPRow;
-  lfloat* sV = sU + rows_per_band * kPairNx;
-  lfloat* sT = sV + rows_per_band * kPairNx + grp * ((rows_per_band + 4) * kPRow + rows_per_band * kRowKWords);
+  lfloat* sT = sW + (rows_per_band + 4) * kPRow + grp * ((rows_per_band + 4) * kPRow + rows_per_band * kRowKWords);
   lfloat* rowk_band = sT + (rows_per_band + 4) * kPRow;
   const lfloat* rowk = rowk_band - k0 * kRowKWords; // indexed by the absolute row
   const size_t fo = (size_t)(live ? m : 0) * ny * kPairNx * 2;
@@ -158,36 +162,20 @@ __global__ __launch_bounds__(kPairThreads) void sweep_pair_kernel(const float* _
   // global rows are [nx][2] = one dwordx4 per point pair i; LDS rows are [half][quad][4]
   constexpr int kXIt = 6; // tracer loads in flight per thread: (4 + 4 rows) x 192 point pairs / 256 threads
   constexpr int kWIt = (kXIt + kPairGroup - 1) / kPairGroup;
-  constexpr int kUIt = (kMaxBandRows * kPairNq + kPairThreads - 1) / kPairThreads; // wind quads per thread
-  const int npair = nrows * (kPairNx / 2), nwind = nb * kPairNq;
+  const int npair = nrows * (kPairNx / 2);
   auto goff = [&](int i) { return ((size_t)(r0 + i / (kPairNx / 2)) * kPairNx + 2 * (i % (kPairNx / 2))) * 2; };
   auto loff = [&](int i) { return (i / (kPairNx / 2)) * kPRow + ppair_off(i % (kPairNx / 2)); };
   for (int base = 0; base < npair; base += kXIt * 256) {
-    f4 x[kXIt], wq[kWIt], uq[kUIt], vq[kUIt];
+    f4 x[kXIt], wq[kWIt];
 #pragma unroll
     for (int j = 0; j < kXIt; ++j) x[j] = ld4(X2 + fo + goff(min(base + j * 256 + tid, npair - 1)));
 #pragma unroll
     for (int j = 0; j < kWIt; ++j) wq[j] = ld4(W2p + goff(min(base + j * kPairThreads + (int)threadIdx.x, npair - 1)));
-    float cu[kUIt], cv = 0.f;
     float rc[kRowKWords] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (base == 0) { // winds and row constants ride in the first batch
-#pragma unroll
-      for (int j = 0; j < kUIt; ++j) {
-        const int iw = min(j * kPairThreads + (int)threadIdx.x, nwind - 1);
-        uq[j] = ld4(ug + (size_t)k0 * kPairNx + 4 * iw); vq[j] = ld4(vg + (size_t)k0 * kPairNx + 4 * iw);
-      }
+    if (base == 0) { // the row constants ride in the first batch
       // (the tables hang off tab_index[m]: a dependent round trip, which must not be waited for before the loads above
       // are on their way)
       __builtin_amdgcn_sched_barrier(0);
-      // pre-scaled by the row's advection constants (those do not depend on the member: only kappa is perturbed,
-      // src/greb.f90:752-753, 840)
-#pragma unroll
-      for (int j = 0; j < kUIt; ++j) {
-        const int kw = k0 + min(j * kPairThreads + (int)threadIdx.x, nwind - 1) / kPairNq;
-        const float c2 = tab.adv_ccx2[kw], c1 = tab.adv_ccx[kw];
-        cu[j] = tab.subcycled[kw] ? c2 * 0.05f : c1 * (1.f / 3.f);
-      }
-      cv = tab.adv_ccy * (1.f / 3.f);
       const int k = k0 + min(tid, nb - 1), sub = tab.subcycled[k]; // the member's constants of the band's rows
       const float d2 = tab.dif_ccx2[k], d1 = tab.dif_ccx[k], a2 = tab.adv_ccx2[k], a1 = tab.adv_ccx[k];
       rc[0] = sub ? d2 : d1; rc[1] = sub ? a2 : a1; rc[2] = tab.dif_ccy; rc[3] = tab.adv_ccy;
@@ -204,15 +192,6 @@ __global__ __launch_bounds__(kPairThreads) void sweep_pair_kernel(const float* _
       if (i < min(npair, base + kXIt * 256)) st4(sW + loff(i), wq[j]);
     }
     if (base == 0) {
-#pragma unroll
-      for (int j = 0; j < kUIt; ++j) {
-        const int iw = j * kPairThreads + (int)threadIdx.x;
-        if (iw < nwind) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { uq[j].v[e] *= cu[j]; vq[j].v[e] *= cv; }
-          st4(sU + 4 * iw, uq[j]); st4(sV + 4 * iw, vq[j]);
-        }
-      }
       if (tid < nb) {
         st4(rowk_band + tid * kRowKWords, f4{{rc[0], rc[1], rc[2], rc[3]}});
         st4(rowk_band + tid * kRowKWords + 4, f4{{rc[4], rc[5], rc[6], rc[7]}});
@@ -246,8 +225,8 @@ __global__ __launch_bounds__(kPairThreads) void sweep_pair_kernel(const float* _
         const int to = v23 < v01 ? m23 : m01;
         l0 += to == 0 ? cb : 0; l1 += to == 1 ? cb : 0; l2 += to == 2 ? cb : 0; l3 += to == 3 ? cb : 0;
         if (to == me) {
-          if (C == 0) pair_chain_row_comp<0>(sT, sW, sU, sV, r0, k0, kb, ny, rk, lane, orow);
-          else pair_chain_row_comp<1>(sT, sW, sU, sV, r0, k0, kb, ny, rk, lane, orow);
+          if (C == 0) pair_chain_row_comp<0>(sT, sW, ug, vg, r0, kb, ny, rk, lane, orow);
+          else pair_chain_row_comp<1>(sT, sW, ug, vg, r0, kb, ny, rk, lane, orow);
         }
       }
     }
@@ -266,7 +245,12 @@ __global__ __launch_bounds__(kPairThreads) void sweep_pair_kernel(const float* _
     const q8 Tm2 = k >= 2 ? ld8g(xr - 2 * kPRow, q) : CT, Tp2 = k <= ny - 3 ? ld8g(xr + 2 * kPRow, q) : CT;
     const q8 Wm1 = k >= 1 ? ld8g(wr - kPRow, q) : zero8(), Wp1 = k <= ny - 2 ? ld8g(wr + kPRow, q) : zero8();
     const q8 Wm2 = k >= 2 ? ld8g(wr - 2 * kPRow, q) : zero8(), Wp2 = k <= ny - 3 ? ld8g(wr + 2 * kPRow, q) : zero8();
-    const f4 xq = ld4(sU + (k - k0) * kPairNx + 4 * q), yq = ld4(sV + (k - k0) * kPairNx + 4 * q);
+    f4 xq = ld4(ug + (size_t)k * kPairNx + 4 * q), yq = ld4(vg + (size_t)k * kPairNx + 4 * q);
+    {
+      const float cu = rk.sub ? rk.adv_cc * 0.05f : rk.adv_cc * (1.f / 3.f), cv = rk.adv_ccy * (1.f / 3.f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xq.v[e] *= cu; yq.v[e] *= cv; }
+    }
     v2 T[12], w[12];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -303,14 +287,16 @@ __global__ void pack_pairs_kernel(const float* __restrict__ state, float* __rest
 
 bool pair_sweep_supported(int nx, int ny) { return nx == kPairNx && ny >= 5 && ny <= kMaxNy; }
 
-// rows per band; LDS = weights (rows+4) x 3 KB + winds rows x 3 KB + per member ((rows+4) x 3 KB + row constants):
-// 4 rows, 4 members: 24 + 12 + 4 x 24 = 133 KB, one 16-wave workgroup per CU
+// rows per band; LDS = weights (rows+4) x 3 KB + per member ((rows+4) x 3 KB + row constants): 4 rows, 1 member:
+// 48 KB.  (Three workgroups would fit a CU by LDS, but the kernel's 223 VGPRs allow two; capped at 168 VGPRs it
+// spills 64 of them and takes 67.8 instead of 52.6 us per launch at 62 members.)  The winds are read by the tasks
+// themselves: every wind value is used by exactly one task.
 static int pair_band_rows() {
   static const int r = tuning_int("GREB_PAIR_ROWS", 4); // -DGREB_TUNING builds only
   return r;
 }
 static size_t pair_lds_bytes(int rows) {
-  return (size_t)((rows + 4) * kPRow + 2 * rows * kPairNx + kPairGroup * ((rows + 4) * kPRow + rows * kRowKWords)) * sizeof(float);
+  return (size_t)((rows + 4) * kPRow + kPairGroup * ((rows + 4) * kPRow + rows * kRowKWords)) * sizeof(float);
 }
 
 hipError_t launch_substep_pairs(const float* X2, const float* W2p, const float* u, const float* v, float* Xnew2,
