@@ -363,6 +363,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (HIP's __fdividef is a plain IEEE division unless the whole file is built with fast-math: ~10 instructions.  The
 // FAST policy wants ONE v_rcp_f32 + one multiply; 19 divisions per point made up 44 % of the point-physics phase.)
 template <bool EXACT> __device__ __forceinline__ float fdiv(float a, float b) { return EXACT ? a / b : a * __builtin_amdgcn_rcpf(b); }
+// (HIP's __logf / __expf are not bare hardware instructions either -- OCML adds denormal scaling and an
+// extended-precision ln2 / log2e product, ~11 instructions per call, 16 calls per quad.  Replacing them by
+// v_log_f32 * ln2 and v_exp_f32(x * log2e) keeps parity (Tsurf 1.42e-5 K RMS) but measured SLOWER, A/B in one gpurun
+// call: point-physics phase 26 600 -> 28 300 cycles, sub-step 4 933 -> 4 990 -- the phase waits on memory, not on
+// these instructions, and the shorter code moved the compiler's load/store scheduling the wrong way.  Not taken.)
 template <bool EXACT> __device__ __forceinline__ float flog(float x) { return EXACT ? logf(x) : __logf(x); }
 template <bool EXACT> __device__ __forceinline__ float fexp(float x) { return EXACT ? expf(x) : __expf(x); }
 template <bool EXACT> __device__ __forceinline__ float fsqrt(float x) { return EXACT ? sqrtf(x) : __builtin_amdgcn_sqrtf(x); }
