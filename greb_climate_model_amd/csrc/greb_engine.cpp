@@ -187,12 +187,12 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
   }
   const size_t np = (size_t)e->np;
   // FAST on a 384-wide grid: both tracers of a member as pairs (greb_pair_sweep.hip); the experiment that diffuses
-  // but does not advect vapour needs per-tracer winds and takes the scalar kernel
-  // Packed arithmetic issues more slowly per instruction, so the pair kernel's polar chains take 71 us per launch
-  // against the scalar kernel's 43 us: below ~40 members the launch is bound by that latency and the scalar kernel
-  // wins (1.31 vs 0.80 yr/s for one member, 29 vs 24 member-yr/s at 32); above it the pair kernel's instruction
-  // count does (47 vs 29 at 64 members, 54 at 128).
-  const bool pairs = e->pairs && nrun >= 40 && !(e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY);
+  // but does not advect vapour needs per-tracer winds and takes the scalar kernel.
+  // Few members: the launch is as long as the 225-sweep polar chain and the scalar kernel, whose workgroups are
+  // smaller, is a little ahead (us per launch, scalar / pairs: 8 members 28.8 / 30.8, 24: 30.3 / 32.4); from ~28
+  // members on the pair kernel's packed single-sweep rows win (32: 38.0 / 33.4, 40: 45.5 / 35.4, 62: 68.0 / 52.6).
+  static const int pair_min = tuning_int("GREB_PAIR_MIN", 28); // -DGREB_TUNING builds only
+  const bool pairs = e->pairs && nrun >= pair_min && !(e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY);
   if (pairs) HIP_TRY(e, launch_pack_pairs(e->state, e->Xa, e->np, nrun, e->stream));
   else HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
   for (int s = 0; s < kNT; ++s) {

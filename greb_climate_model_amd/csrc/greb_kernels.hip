@@ -47,8 +47,11 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
   constexpr bool kWinds = MODE != kChainDif;
   lfloat* sU = sW + nrows * nx; // with winds: band rows k0..k1
   lfloat* sV = sU + (kWinds ? (k1 - k0) * nx : 0);
-  lfloat* scratch = sV + (kWinds ? (k1 - k0) * nx : 0); // [nwaves][4*nx]
-  lfloat* rowk = scratch + 4 * 4 * nx;                              // [ny][kRowKWords]
+  // per wave: the chain rows' sub-cycled results (greb_stencil.h: chain_row_scratch); the band's row constants
+  const int per_wave = chain_row_scratch(nx);
+  lfloat* scratch = sV + (kWinds ? (k1 - k0) * nx : 0);
+  lfloat* rowk_band = scratch + 4 * per_wave;                       // [rows_per_band][kRowKWords]
+  const lfloat* rowk = rowk_band - k0 * kRowKWords;                 // indexed by the absolute row
   const size_t fo = (size_t)b * nx * ny;
   const size_t fw = (size_t)(wmod ? b % wmod : b) * nx * ny;
   const size_t fu = uv_shared ? 0 : fo;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
     }
     if (base == 0) {
       __builtin_amdgcn_sched_barrier(0);
-      stage_row_consts(rowk, tab, ny);
+      stage_row_consts(rowk_band, tab, k0, k1);
     }
 #pragma unroll
     for (int j = 0; j < kIt; ++j) {
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ T1
     const RowK rk = row_consts((const lfloat*)rowk, k);
     if (!is_chain_row(rk, MODE)) continue;
     if ((ci++ % nwaves) == wave)
-      chain_row<STRICT>(X, W, U, V, rk, k, nq, ny, lane, MODE, scratch + wave * 4 * nx, dX + fo + (size_t)k * nx);
+      chain_row<STRICT>(X, W, U, V, rk, k, nq, ny, lane, MODE, scratch + wave * per_wave, dX + fo + (size_t)k * nx);
   }
   // everything else: quads, all threads
   for (int i = threadIdx.x; i < (k1 - k0) * nq; i += blockDim.x) {
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(kStreamThreads) void diffusion_stream_kernel(const 
   lfloat* scratch = sW + ny * nx;      // [2 halves][2*nx]: diffusion chains use two row buffers each
   lfloat* rowk = scratch + 2 * 2 * nx; // [ny][kRowKWords]
   lfloat* chainlist = rowk + ny * kRowKWords; // [ny] row indices of the chain rows
-  stage_row_consts(rowk, *tabp, ny);
+  stage_row_consts(rowk, *tabp, 0, ny);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int nchain = 0; // uniform: every thread scans the (global, cached) table once
   for (int kk = 0; kk < ny; ++kk)
@@ -261,12 +264,12 @@ static size_t stream_lds_bytes(int nx, int ny) { return (size_t)(2 * nx * ny + 2
 static bool stream_fits(int nx, int ny) { return nx == 96 && ny == 48; }
 
 static size_t sweep_lds_bytes(int nx, int rows, int halo, int extra_fields) {
-  return (size_t)(((rows + 2 * halo) * 2 + rows * extra_fields) * nx + 4 * 4 * nx + kMaxNy * kRowKWords) * sizeof(float);
+  return (size_t)(((rows + 2 * halo) * 2 + rows * extra_fields) * nx + 4 * chain_row_scratch(nx) + rows * kRowKWords) * sizeof(float);
 }
 static int pick_band_rows(int nx, int ny, int halo, int extra_fields) {
   // whole field per workgroup when it fits ~44 KB (3+ workgroups share a CU's 160 KB); wide
   // grids get latitude bands of <= 64 KB
-  size_t limit = nx <= 128 ? 44 * 1024 : 64 * 1024;
+  size_t limit = nx <= 128 ? 44 * 1024 : 48 * 1024;
   limit = (size_t)tuning_int("GREB_BAND_LIMIT_KB", (int)(limit / 1024)) * 1024; // -DGREB_TUNING builds only
   int rows = ny;
   while (rows > 2 && sweep_lds_bytes(nx, rows, halo, extra_fields) > limit) rows = (rows + 1) / 2;

@@ -647,7 +647,7 @@ struct Circ {
       const int g = i / RS, o = i % RS; // buffer g >> 1, lower / upper guard g & 1
       lds[(g >> 1) * XB + (g & 1) * (NY + 1) * RS + o] = 0.f;
     }
-    stage_row_consts(lds + kOffRowK, *tab, NY);
+    stage_row_consts(lds + kOffRowK, *tab, 0, NY);
     for (int i = threadIdx.x; i < NP / 4; i += kThreads)
       st8(lds + kOffW + (i / NQ) * RS, i % NQ, zip(ld4(wz_air + 4 * i), ld4(wz_vapor + 4 * i)));
   }

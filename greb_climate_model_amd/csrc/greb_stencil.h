@@ -41,10 +41,11 @@ struct RowK {
 // flight across their compute phase (prefetch) must not read the tables from global memory there:
 // s_waitcnt vmcnt is in-order, so one table load would wait for every prefetch ahead of it.
 constexpr int kRowKWords = 8;
-__device__ __forceinline__ void stage_row_consts(lfloat* dst, const RowTables& tab, int ny) {
-  for (int k = threadIdx.x; k < ny; k += blockDim.x) {
+// rows k_begin .. k_end-1 to dst[0 ..]
+__device__ __forceinline__ void stage_row_consts(lfloat* dst, const RowTables& tab, int k_begin, int k_end) {
+  for (int k = k_begin + threadIdx.x; k < k_end; k += blockDim.x) {
     const int sub = tab.subcycled[k];
-    lfloat* d = dst + k * kRowKWords;
+    lfloat* d = dst + (k - k_begin) * kRowKWords;
     d[0] = sub ? tab.dif_ccx2[k] : tab.dif_ccx[k];
     d[1] = sub ? tab.adv_ccx2[k] : tab.adv_ccx[k];
     d[2] = tab.dif_ccy; d[3] = tab.adv_ccy;
@@ -320,16 +321,20 @@ __device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfl
   wave_lds_sync();
 }
 
+// floats of LDS one wave needs for chain_row's sub-cycled results
+__host__ __device__ constexpr int chain_row_scratch(int nx) { return (nx == 384 ? 2 : 4) * nx; }
+
 // complete update of one chain row by one wave.  out_row (any address space): the X_new row
 // (fused) or the dX row (dif / adv only).
 template <bool STRICT, typename OutP>
 __device__ void chain_row(const Rows& X, const Rows& W, const Rows& U, const Rows& V, const RowK& rk, int k,
                           int nq, int ny, int lane, int mode, lfloat* scratch /* 4*nx */, OutP out_row) {
   const int nx = 4 * nq;
+  // a 384-point row iterates in registers and only parks its result; other rows ping-pong between two buffers
   lfloat* dA = scratch;          // diffusion T1h
   lfloat* dB = scratch + nx;
-  lfloat* aA = scratch + 2 * nx; // advection T1h
-  lfloat* aB = scratch + 3 * nx;
+  lfloat* aA = scratch + (nx == 384 ? 1 : 2) * nx; // advection T1h
+  lfloat* aB = aA + nx;
   const bool do_dif = mode != kChainAdv, do_adv = mode != kChainDif;
   if (nx == 384) { // the row fits the wave's registers, 6 points per lane
     if (do_dif) chain_lon_regs<STRICT, 6>(X.row(k), W.row(k), nullptr, rk.dif_cc, rk.dif_time2, false, lane, dA);

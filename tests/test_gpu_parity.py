@@ -324,7 +324,7 @@ def test_chain_clamp_g384(eng_mod, oracle_lib, inputs384):
 @pytest.mark.parametrize("mode", ["strict", "fast", "pairs"])
 def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
     """BASELINE config 3 in miniature against the REFERENCE compiled at 384x192 (g384_short.npz): 1+2 yr, 2xCO2.
-    strict / fast: 2 members on the scalar any-grid kernel; pairs: 40 members, the engine's threshold for the
+    strict / fast: 2 members on the scalar any-grid kernel; pairs: 40 members (the engine takes the pair kernel from 28 on), the
     (Tair,q)-pair kernel of greb_pair_sweep.hip.  Months 1, 12, 24 in full, every month by zonal means and polar rows."""
     from greb_climate_model_amd import abi
     g = load_golden("g384_short.npz")
