@@ -1,7 +1,9 @@
-// greb_chain6.h -- the sub-cycled zonal sweep of a 384-point row held 6 points per lane, as 36 instructions.
+// greb_chain6.h -- the sub-cycled zonal sweep of a latitude circle held 6 points per lane, as 36 instructions.
 //
-// The long polar chains of the 384x192 grid (src/greb.f90:651-719, :837-911; up to 225 -- 1 800 for kappa < 7.27e5 --
-// DEPENDENT sweeps per diffusion call) are executed by one wavefront per (row, tracer), and a lone wavefront issues one
+// The circle is either the whole wavefront (64 lanes x 6 = 384 points: the 384x192 grid, one chain per wave) or one
+// DPP row of 16 lanes (16 x 6 = 96 points: the 96x48 grid, four independent chains per wave -- the fused engine's
+// polar rows).  The long polar chains (src/greb.f90:651-719, :837-911; at 384x192 up to 225 -- 1 800 for
+// kappa < 7.27e5 -- DEPENDENT sweeps per diffusion call) are latency: a lone wavefront issues one
 // vector instruction per ~5 cycles whatever the instruction is: the chain's latency is its instruction count.  FAST
 // arithmetic only (greb_stencil.h: chain_lon_regs): during a chain the weights, the row constant and the wind are
 // fixed, so the increment of point c is a fixed linear form in the six differences around it,
@@ -18,8 +20,8 @@
 //     a lane boundary, cost a DPP subtract;
 //   * input and output points use two register sets (A -> B, B -> A) and the loop itself is part of the asm
 //     statement (chain_sweeps6), so nothing is copied at the loop edge.
-// Same operands, same operations, same order per point as differencing a refreshed T halo and summing m = 0..5
-// (pair_chain_row in greb_pair_sweep.hip is that form on (Tair,q) pairs): results are bit-identical to it.
+// Same operands, same operations, same order per point as differencing a refreshed T halo and summing m = 0..5 (the
+// form chain_increments6 below spells out in C++): results are bit-identical to it.
 //
 // The body addresses halves of the point / difference / increment pairs, which inline-asm operands cannot express,
 // so those live in FIXED registers v64..v90 (the points bound with "{vN}" constraints, the rest clobbered); the

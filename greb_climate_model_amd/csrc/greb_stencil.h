@@ -307,7 +307,7 @@ __device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfl
     // FAST: the weights, the row constant and the wind do not change during the chain, so the increment of point c
     // is a fixed linear form in the six differences e[m] = T[m+1] - T[m] around it (coefficients K, built once
     // before the loop): 6 x (1 mul + 5 fma) per sweep instead of the edge-flux form's 22 products + 6 x 6.
-    static_assert(STRICT || P == 6, "chain_sweep6 is written for 6 points per lane");
+    static_assert(STRICT || P == 6, "chain_run6 (greb_chain6.h) is written for 6 points per lane");
     float own[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) own[i] = T[3 + i];
