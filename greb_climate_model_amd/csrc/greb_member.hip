@@ -535,6 +535,7 @@ __device__ __forceinline__ void chain_substep_strict(lfloat* lds, int cur, int p
 struct QuadChain {
   ChainK kd, ka;             // d[i] = sum_m K[i][m] e[i+m] (greb_chain6.h): zonal diffusion, zonal advection
   float w0[6], W1[6], W2[6]; // weights of the own row and of the two rows towards the interior
+  float own[6];              // the lane's points: loaded once per circulation call, then carried from sub-step to sub-step
   float cv[6];               // the latitudinal advection coefficient of the point: (ccy/3) min(v,0) south, -(ccy/3) max(v,0) north
   float ccy;                 // dif_ccy
   int at[3];                 // float offsets, within a row, of the lane's three longitude pairs (+ its tracer)
@@ -543,7 +544,7 @@ struct QuadChain {
   bool calm;                 // vapour lane of an experiment that diffuses vapour without advecting it
 };
 
-__device__ __forceinline__ void quad_chain_setup(const lfloat* lds, int lane, bool calm_q, QuadChain& c) {
+__device__ __forceinline__ void quad_chain_setup(const lfloat* lds, int cur, int lane, bool calm_q, QuadChain& c) {
   const int r = lane >> 4, j = lane & 15, pole = r >> 1, C = r & 1;
   const int k = pole ? NY - 1 : 0, k1 = pole ? k - 1 : k + 1, k2 = pole ? k - 2 : k + 2; // towards the interior
   const RowK rk = row_consts((const lfloat*)(lds + kOffRowK), k);
@@ -568,6 +569,7 @@ __device__ __forceinline__ void quad_chain_setup(const lfloat* lds, int lane, bo
     constexpr int i = I, p = 3 + i;
     const int o = c.at[i >> 1] + (i & 1) * 2;
     c.w0[i] = w[p];
+    c.own[i] = lds[kOffX + cur * XB + c.row[0] + o];
     c.W1[i] = Wc[c.row[1] + o];
     c.W2[i] = Wc[c.row[2] + o];
     const float u = lds[kOffWX + k * NX + 6 * j + i], v = lds[kOffWY + k * NX + 6 * j + i]; // raw winds in the polar rows
@@ -590,11 +592,13 @@ __device__ __forceinline__ void quad_chain_setup(const lfloat* lds, int lane, bo
 
 __device__ __forceinline__ void quad_chain_substep(lfloat* lds, int cur, QuadChain& c) {
   const lfloat* Xc = lds + kOffX + cur * XB;
+  // (the own row is this wave's alone: what it stored last sub-step is what it would read now, so the chain starts
+  // without an LDS round trip; the neighbour rows are requested here and not needed before the epilogue)
   float own[6], T1[6], T2[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int o = c.at[i >> 1] + (i & 1) * 2;
-    own[i] = Xc[c.row[0] + o];
+    own[i] = c.own[i];
     T1[i] = Xc[c.row[1] + o];
     T2[i] = Xc[c.row[2] + o];
   }
@@ -614,7 +618,8 @@ __device__ __forceinline__ void quad_chain_substep(lfloat* lds, int cur, QuadCha
     const float dd = c.w0[i] * ((Td[i] - own[i]) + ddy);
     float da = (Ta[i] - own[i]) + day;
     if (c.calm) da = 0.f; // orig :562
-    out[c.at[i >> 1] + (i & 1) * 2] = (own[i] + dd) + da;
+    c.own[i] = (own[i] + dd) + da;
+    out[c.at[i >> 1] + (i & 1) * 2] = c.own[i];
   }
 }
 
@@ -667,7 +672,7 @@ struct Circ {
     BulkTasks tasks;
     QuadChain quad;
     if constexpr (!kPolar) tasks = make_tasks<STRICT>(WAVE, lane);
-    else if constexpr (!STRICT) quad_chain_setup(lds, lane, calm_q, quad);
+    else if constexpr (!STRICT) quad_chain_setup(lds, cur, lane, calm_q, quad);
 #pragma unroll 1
     for (int tt = 0; tt < nsub; ++tt) {
 #ifdef GREB_TUNING
