@@ -241,15 +241,15 @@ __device__ __forceinline__ void chain_increments6(const float (&o)[6], const Cha
 // the wavefront.
 template <bool ROW16>
 __device__ __forceinline__ void chain_run6(float (&T)[6], const ChainK& c, int time2) {
-  int rem = __builtin_amdgcn_readfirstlane(time2);
-  while (rem > 0) {
-    rem = chain_sweeps6<ROW16>(T, c, rem);
-    if (rem == 0) break;
+  int rem = chain_sweeps6<ROW16>(T, c, __builtin_amdgcn_readfirstlane(time2));
+  // (the rare path is kept out of the common one: written as one loop around the asm statement, the compiler surrounds
+  // every chain with its flag and copy bookkeeping, ~25 instructions)
+  while (__builtin_expect(rem > 0, 0)) {
     float d[6];
     chain_increments6<ROW16>(T, c, d);
 #pragma unroll
     for (int i = 0; i < 6; ++i) T[i] = T[i] + ((d[i] <= -T[i]) ? -0.9f * T[i] : d[i]); // the reference's select
-    --rem;
+    if (--rem > 0) rem = chain_sweeps6<ROW16>(T, c, rem);
   }
 }
 

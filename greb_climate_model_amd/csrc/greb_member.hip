@@ -268,7 +268,7 @@ struct BulkTasks { TaskAddr t[3]; };
 //   S1  rows 9, 38                                       : 48 tasks, one pass                   (223)
 //   F1  rows 26 .. 37                                    : 288 tasks, 4.5 passes                (156)
 // Waves w and w+4 share a SIMD; the polar rows (a dependent chain of 8 + 1 Jacobi sweeps per sub-step) have their own
-// wave(s): wave 2 in FAST, waves 2 and 3 in STRICT.  The SIMD's issue arbiter favours the OLDER wave; the younger one runs in the
+// wave(s): wave 6 in FAST, waves 2 and 3 in STRICT.  The SIMD's issue arbiter favours the OLDER wave; the younger one runs in the
 // slots that leaves, and once the older wave is done the younger runs alone at a single wave's issue rate (one
 // instruction per ~5 cycles at best, ~6-7 with its LDS waits) -- so the older wave of a pair carries the larger
 // share and the two should finish together.  In-kernel stamps (tools/stamp_member.py) give each wave's busy time
@@ -276,33 +276,38 @@ struct BulkTasks { TaskAddr t[3]; };
 // tools/ubench/valu_rate.hip; a scalar one ~2.3-2.7).
 enum { kNone = 0, kS1 = 1, kF1 = 2, kST = 3, kFT = 4 };
 struct Pass { int kind, index; };
-// FAST: wave 2 alone runs all four polar chains (quad_chain_substep: 36-instruction sweeps, ~3 050 busy cycles per
-// sub-step where two waves took ~4 400 each), wave 3 is a seventh bulk wave.  The chain wave is the OLDER wave of
-// SIMD 2 and issues one instruction every ~5 cycles for as long as it runs, so its partner gets little of the pipe
-// until it is done.  Measured sub-step times (tools/deal_search.py: in-kernel stamps, 512 members, one gpurun call;
-// slots w0 w1 w3 | w4 w5 w6 w7, S = ST, T = FT, H = S1, F = F1):
-//     S0+F0 S2+H  T2+F1+F2 | S1    T0    T1+F3 F4      4 932   <- the table below
-//     S0+F0 S1+H  T2+F1+F2 | S2    T0    T1+F3 F4      4 929
-//     S0+F0 S2+H  T2+F1    | S1    T0    T1+F3 F2+F4   4 975
-//     S0+F0 S2+F1 T2+H+F2  | S1    T0    T1+F3 F4      4 974
-//     S0+F0 S2+H  T2+F1+F2 | S1    T0    T1    F3+F4   5 070   (wave 7 waits behind wave 3's three passes)
-//     S0+F0 S2+T0 H+F1+F2  | S1    T2    T1    F3+F4   5 094
-//     S0+H  S2+F0 T2+F1+F2 | S1    T0    T1+F3 F4      5 103
-//     S0    S2+H  T2+F1    | S1+F0 T0    T1+F2 F3+F4   5 273
-//     S0+F0 S2+H  F1+F2+F3 | S1    T0    T1    T2+F4   5 509
-//     S0+F0 S2+H  T2+F1+F2 | S1    T1+F3 T0    F4      5 647
-//     S0    S2+F0 H+F1+F2  | S1    T0    T1+T2 F3+F4   5 988   (two FT passes behind the chain wave)
-// With it the busiest wave of each SIMD is busy 4 470 / 4 580 / 4 760 / 4 290 cycles: within 5 % of a perfect balance.
+// FAST: ONE wave runs all four polar chains (quad_chain_substep: 36-instruction sweeps, ~2 600 busy cycles per
+// sub-step when it has the SIMD to itself, where two waves took ~4 400 each) and there are seven bulk waves.  The chain
+// wave issues one instruction every ~5 cycles for as long as it runs; as the OLDER wave of its SIMD it leaves its
+// partner little of the pipe until it is done, as the YOUNGER one (wave 6) it fills the slots its partner leaves and
+// both finish together.  Measured sub-step times (tools/deal_search.py: in-kernel stamps, 512 members, one gpurun call
+// per group; slots w0 w1 w2 w3 | w4 w5 w6 w7, C = the chains, S = ST, T = FT, H = S1, F = F1):
+//   chains on wave 6 (younger wave of SIMD 2)
+//     S0+F0 S2+F1 T1+F3 T2+H+F2 | S1    T0    C     F4      4 773   <- the table below
+//     S0+F0 S1+H  T1+F3 T2+F1+F2| S2    T0    C     F4      4 814
+//     S0+F0 S2+H  T1+F3 T2+F1+F2| S1    T0    C     F4      4 817
+//     S0+F0 S2+H  T1+F3 T2+F1   | S1    T0    C     F2+F4   4 886
+//     S0+F0 S2+H  T1+F3+F4 T2+F1+F2 | S1 T0   C     -       5 315   (the chains starve behind three passes)
+//     S0+F0 S2+H  T1+F3 T2+F1+F2| S1    T0+F4 C     -       5 665
+//   chains on wave 2 (older wave of SIMD 2), same call: 4 900
+//     S0+F0 S2+H  C     T2+F1+F2| S1    T0    T1+F3 F4      4 900 ... 4 932
+//     S0+F0 S2+H  C     T2+F1   | S1    T0    T1+F3 F2+F4   4 975
+//     S0+F0 S2+F1 C     T2+H+F2 | S1    T0    T1+F3 F4      4 974
+//     S0+F0 S2+H  C     T2+F1+F2| S1    T0    T1    F3+F4   5 070   (wave 7 waits behind wave 3's three passes)
+//     S0+F0 S2+T0 C     H+F1+F2 | S1    T2    T1    F3+F4   5 094
+//     S0    S2+F0 C     H+F1+F2 | S1    T0    T1+T2 F3+F4   5 988   (two FT passes behind the chain wave)
+//   chains on wave 7 (younger wave of SIMD 3): 5 432
+// With the table below the busiest wave of each SIMD is busy 4 325 / 4 348 / 4 379 / 4 368 cycles: balanced to 1 %.
 __host__ __device__ constexpr Pass deal_fast(int wave, int i) {
   constexpr Pass none{kNone, 0};
 #if defined(GREB_TUNING) && defined(GREB_DEAL_FAST) // tools/deal_search.py: a deal given on the compiler command line
   constexpr Pass t[8][3] = {GREB_DEAL_FAST};
 #else
   constexpr Pass t[8][3] = {
-      /* w0 */ {{kST, 0}, {kF1, 0}, none},     /* w1 */ {{kST, 2}, {kS1, 0}, none},
-      /* w2 */ {none, none, none},             /* w3 */ {{kFT, 2}, {kF1, 1}, {kF1, 2}},
+      /* w0 */ {{kST, 0}, {kF1, 0}, none},     /* w1 */ {{kST, 2}, {kF1, 1}, none},
+      /* w2 */ {{kFT, 1}, {kF1, 3}, none},     /* w3 */ {{kFT, 2}, {kS1, 0}, {kF1, 2}},
       /* w4 */ {{kST, 1}, none, none},         /* w5 */ {{kFT, 0}, none, none},
-      /* w6 */ {{kFT, 1}, {kF1, 3}, none},     /* w7 */ {{kF1, 4}, none, none}};
+      /* w6 */ {none, none, none},             /* w7 */ {{kF1, 4}, none, none}};
 #endif
   return t[wave][i];
 }
@@ -328,8 +333,13 @@ __host__ __device__ constexpr Pass deal_strict(int wave, int i) {
 }
 template <bool STRICT>
 __host__ __device__ constexpr Pass deal(int wave, int i) { return STRICT ? deal_strict(wave, i) : deal_fast(wave, i); }
+#if defined(GREB_TUNING) && defined(GREB_POLAR_WAVE_FAST) // tools/deal_search.py: which wave runs the FAST polar chains
+constexpr int kPolarWaveFast = GREB_POLAR_WAVE_FAST;
+#else
+constexpr int kPolarWaveFast = 6;
+#endif
 template <bool STRICT>
-__host__ __device__ constexpr bool is_polar_wave(int wave) { return wave == 2 || (STRICT && wave == 3); }
+__host__ __device__ constexpr bool is_polar_wave(int wave) { return STRICT ? (wave == 2 || wave == 3) : wave == kPolarWaveFast; }
 
 // every pass of every kind is dealt to exactly one wave slot (a deal that drops or doubles a pass would still "run")
 template <bool STRICT>

@@ -5,8 +5,8 @@
                                              greb_climate_model_amd/variants/ (git-ignored, travels with gpurun)
   python tools/deal_search.py run [members]  on the GPU box: tools/stamp_member.py for every built variant, one line each
 
-A deal is written as seven wave slots "w0 w1 w3 w4 w5 w6 w7" (wave 2 runs the polar chains), each a '+'-joined list of
-passes: S0..S2 = ST (two sub-cycled rows), T0..T2 = FT (two full rows), H = S1, F0..F4 = F1, '-' = idle."""
+A deal is written as the seven bulk wave slots in wave order (the polar wave -- "P<w>:" prefix, default wave 6 -- is
+left out), each a '+'-joined list of passes: S0..S2 = ST (two sub-cycled rows), T0..T2 = FT (two full rows), H = S1, F0..F4 = F1, '-' = idle."""
 import os
 import subprocess
 import sys
@@ -16,22 +16,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARDIR = os.path.join(ROOT, "greb_climate_model_amd", "variants")
 
-DEALS = {
-    "c":     "S0+F0 S2+H  T2+F1+F2 S1 T0 T1+F3 F4",
-    "d1":    "S0+F0 S2+H  T2+T1    S1 T0 F1+F3+F4 F2",
-    "d2":    "S0+F0 S2+H  T2+T1    S1 T0 F1+F2+F3 F4",
-    "d3":    "S0+F0 S2+H  T2+T1    S1 T0 F1+F2 F3+F4",
-    "d4":    "S0+F0 S2+H  T2+F1+F2 S1 T0 F3+F4 T1",
-    "d5":    "S0+F0 S2+F1 T2+T1    S1 T0 H+F2+F3 F4",
-    "d6":    "S0+F0 S2+T0 T2+F1    S1 H+F2 T1+F3 F4",
-    "d7":    "S0+F0 S2+H  T2+F1+F2 S1+F4 T0 T1+F3 -",
+DEALS = {  # a leading "P<w>:" puts the polar chains on wave w (default 6); the slot list omits that wave
+    "p6g":   "P6:S0+F0 S2+F1 T1+F3 T2+H+F2 S1 T0 F4",
+    "p6":    "P6:S0+F0 S2+H T1+F3 T2+F1+F2 S1 T0 F4",
+    "p6i":   "P6:S0+F0 S1+H T1+F3 T2+F1+F2 S2 T0 F4",
+    "p2c":   "P2:S0+F0 S2+H T2+F1+F2 S1 T0 T1+F3 F4",
+    "p7":    "P7:S0+F0 S2+H T1+F3 T2+F1+F2 S1 T0 F4",
 }
 
 
+def polar_wave(deal: str) -> int:
+    return int(deal.split(":")[0][1:]) if deal.startswith("P") else 6
+
+
 def table(deal: str) -> str:
-    slots = deal.split()
+    pw = polar_wave(deal)
+    slots = deal.split(":")[-1].split()
     assert len(slots) == 7, deal
-    waves = slots[:2] + ["-"] + slots[2:]
+    waves = slots[:pw] + ["-"] + slots[pw:]
     rows = []
     for w in waves:
         ps = [] if w == "-" else w.split("+")
@@ -48,7 +50,8 @@ def table(deal: str) -> str:
 def build_one(name: str) -> str:
     from greb_climate_model_amd import build
     out = os.path.join(VARDIR, f"libgreb_hip_deal_{name}.so")
-    cmd = [build.hipcc(), *build.HIPCC_FLAGS, "-DGREB_TUNING", "-DGREB_DEAL_FAST=" + table(DEALS[name]), "-o", out,
+    cmd = [build.hipcc(), *build.HIPCC_FLAGS, "-DGREB_TUNING", "-DGREB_DEAL_FAST=" + table(DEALS[name]),
+           f"-DGREB_POLAR_WAVE_FAST={polar_wave(DEALS[name])}", "-o", out,
            *[os.path.join(build.CSRC, s) for s in build.SOURCES]]
     subprocess.run(cmd, check=True, cwd=build.CSRC, stdout=subprocess.DEVNULL)
     return out

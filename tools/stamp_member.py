@@ -53,5 +53,5 @@ sub = np.median(circ[:, 0]) / ns / nsb
 print(f"sub-step = {sub:.0f} cycles = {sub / clk:.3f} us; per wave busy cycles per sub-step and barrier wait share:")
 for w in range(8):
     b = np.median(busy[:, w]) / ns / nsb
-    print(f"  wave {w} (SIMD {w % 4}, {'pole' if w in (2, 3) else 'bulk'}): busy {b:6.0f} cyc  waits {100 * (1 - b / sub):4.1f} %")
+    print(f"  wave {w} (SIMD {w % 4}, {'polar chains' if w == 6 else 'bulk'}): busy {b:6.0f} cyc  waits {100 * (1 - b / sub):4.1f} %")
 print(f"member-years/s at this launch time: {M / (np.median(rt[:, 0]) / 1e8) / max(1, -(-M // 256)):.0f}")
