@@ -18,10 +18,12 @@ VARDIR = os.path.join(ROOT, "greb_climate_model_amd", "variants")
 
 DEALS = {  # a leading "P<w>:" puts the polar chains on wave w (default 6); the slot list omits that wave
     "p6g":   "P6:S0+F0 S2+F1 T1+F3 T2+H+F2 S1 T0 F4",
-    "p6":    "P6:S0+F0 S2+H T1+F3 T2+F1+F2 S1 T0 F4",
-    "p6i":   "P6:S0+F0 S1+H T1+F3 T2+F1+F2 S2 T0 F4",
-    "p2c":   "P2:S0+F0 S2+H T2+F1+F2 S1 T0 T1+F3 F4",
-    "p7":    "P7:S0+F0 S2+H T1+F3 T2+F1+F2 S1 T0 F4",
+    "q1":    "P6:S0+F0 S2+F1 T1+F3 T2+F2 S1 T0 H+F4",
+    "q2":    "P6:S0+F0 S2+F1 T1+F3 T2+H S1 T0 F2+F4",
+    "q3":    "P6:S0+F0 S2+H T1+F3 T2+F1 S1 T0+F2 F4",
+    "q4":    "P6:S0+H S2+F1 T1+F3 T2+F0+F2 S1 T0 F4",
+    "q5":    "P6:S0+F0 S2+F1 T1+H T2+F3+F2 S1 T0 F4",
+    "q6":    "P6:S0+F0 S2+F1 T1+F3 T0+H+F2 S1 T2 F4",
 }
 
 
