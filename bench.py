@@ -256,7 +256,7 @@ def main():
                                     "achieved_tflops_per_gpu": round(value / world * gflop_my / 1e3, 2),
                                     "peak_fp32_vector_tflops": 157.3,
                                     "frac": round(value / world * gflop_my / 1e3 / 157.3, 4),
-                                    "bound": "VALU pipe: the four SIMDs of the sub-step loop are balanced to within 5 % (DESIGN.md 4.1)"}
+                                    "bound": "VALU pipe: the four SIMDs of the sub-step loop are balanced to 1 % (DESIGN.md 4.1)"}
         if roof is not None:
             out["roofline"] = roof
         if delivered is not None:
