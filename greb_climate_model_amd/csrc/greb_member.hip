@@ -855,6 +855,9 @@ __global__ __launch_bounds__(kThreads) void member_kernel(MemberArgs a) {
     // per member-year).  What the slower variants share: vector-memory operations retire in order, so the loop's waits
     // for its loads also wait for the previous pass's stores; in the form below the compiler gets away with
     // s_waitcnt vmcnt(6) where the variants end up at vmcnt(0).  (All A/B runs in one gpurun call: boxes differ.)
+    // Also measured: the next quad's operands requested BETWEEN the arithmetic of the current quad and its stores
+    // (physics_load / physics_compute / physics_store, the inputs dead by then): 116 + 56 live VGPRs of operands and
+    // results still spill 68 registers at the 256 cap, and the phase takes 41 600 cycles instead of 24 900.
 #pragma unroll 1
     for (int qd = tid; qd < NP / 4; qd += kThreads) {
 #ifdef GREB_TUNING
