@@ -124,7 +124,7 @@ __device__ void pair_chain_row_comp(const lfloat* sT, const lfloat* sW, const fl
 // workgroup has nobody to overlap them with); 3 or 4 members cap the kernel at 168 / 128 VGPRs where it wants 223
 // (spills: 76 / 186 us).  The code keeps the group size as a parameter.
 constexpr int kPairGroup = 1;
-constexpr int kMaxBandRows = 4; // (rows + 4) x 192 point pairs = kXIt x 256 tracer loads per thread
+constexpr int kMaxBandRows = 8; // 12 staged rows x 3 KB x (tracers + weights) = 72 KB: still two workgroups per CU
 constexpr int kPairThreads = 256 * kPairGroup;
 
 __global__ __launch_bounds__(kPairThreads) void sweep_pair_kernel(const float* __restrict__ X2, const float* __restrict__ W2p,
@@ -291,9 +291,14 @@ bool pair_sweep_supported(int nx, int ny) { return nx == kPairNx && ny >= 5 && n
 // 48 KB.  (Three workgroups would fit a CU by LDS, but the kernel's 223 VGPRs allow two; capped at 168 VGPRs it
 // spills 64 of them and takes 67.8 instead of 52.6 us per launch at 62 members.)  The winds are read by the tasks
 // themselves: every wind value is used by exactly one task.
-static int pair_band_rows() {
-  static const int r = tuning_int("GREB_PAIR_ROWS", 4); // -DGREB_TUNING builds only
-  return r;
+// A band stages rows + 4 rows to update rows: the larger the band, the less of the staging is halo (2x at 4 rows, 1.5x
+// at 8) -- and the fewer, longer workgroups there are to fill the chip with.  Measured (us per launch, rows 4 / 6 / 8):
+// 40 members 35.1 / 36.8 / 45.4, 48: 40.6 / 40.8 / 46.0, 56: 46.8 / 45.5 / 46.1, 62: 52.0 / 50.3 / 47.8,
+// 96: 71.1 / 69.2 / 64.2, 128: 90.7 / 87.8 / 80.1.
+static int pair_band_rows(int n_members) {
+  static const int forced = tuning_int("GREB_PAIR_ROWS", 0); // -DGREB_TUNING builds only
+  if (forced > 0) return forced;
+  return n_members >= 58 ? 8 : (n_members >= 50 ? 6 : 4);
 }
 static size_t pair_lds_bytes(int rows) {
   return (size_t)((rows + 4) * kPRow + kPairGroup * ((rows + 4) * kPRow + rows * kRowKWords)) * sizeof(float);
@@ -301,7 +306,7 @@ static size_t pair_lds_bytes(int rows) {
 
 hipError_t launch_substep_pairs(const float* X2, const float* W2p, const float* u, const float* v, float* Xnew2,
                                 const RowTables* tabs, const int* tab_index, int ny, int n_members, hipStream_t s) {
-  const int rows = pair_band_rows(), bands = (ny + rows - 1) / rows;
+  const int rows = pair_band_rows(n_members), bands = (ny + rows - 1) / rows;
   if (rows < 1 || rows > kMaxBandRows) return hipErrorInvalidValue;
   const size_t lds = pair_lds_bytes(rows);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_pair_kernel),

@@ -344,7 +344,7 @@ def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
         assert np.array_equal(mon[0], mon[1])  # replicas agree bit for bit
 
 
-@pytest.mark.parametrize("mode", ["strict", "fast", "pairs"])
+@pytest.mark.parametrize("mode", ["strict", "fast", "pairs", "pairs60"])
 def test_config5_perturbed_members_g384_vs_reference(eng_mod, inputs384, mode):
     """BASELINE config 5 in miniature: perturbed-physics members at 384x192 -- per-member RowTables (own kappa),
     own flux corrections (shared_corr = false), the multi-launch engine and, in `pairs`, the pair kernel -- against
@@ -353,7 +353,8 @@ def test_config5_perturbed_members_g384_vs_reference(eng_mod, inputs384, mode):
     from greb_climate_model_amd import abi
     g = load_golden("g384_physpar.npz")
     ov = g["overrides"]
-    reps = 8 if mode == "pairs" else 1  # 40 members: the pair kernel
+    # 40 members: the pair kernel with 4-row bands; 60 members: with 8-row bands (greb_pair_sweep.hip: pair_band_rows)
+    reps = {"pairs": 8, "pairs60": 12}.get(mode, 1)
     overrides = [dict(zip(("da_ice", "a_no_ice", "a_cloud", "kappa"), map(float, ov[m % 5]))) for m in range(5 * reps)]
     e = eng_mod.Engine(inputs384, abi.default_params(ipx=380, ipy=152), n_members=5 * reps, overrides=overrides,
                        strict=mode == "strict")
