@@ -359,10 +359,27 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
                                     "finite": ok, "bound": "latency of one wave's 225-sweep polar chain per launch"}
     ov = ensemble.perturbed_physics(64, p)
     as_dicts = lambda rows: [dict(zip(ensemble.PERTURBED, map(float, row))) for row in rows]
-    r, dt, ok = year_rate(64, as_dicts(ov))
     slow = ov[:, 3] < 7.27e5
-    out["config5_64_members"] = {"member_years_per_s": round(r, 2), "finite": ok, "members_with_1800_sweep_polar_rows": int(slow.sum()),
-                                 "bound": "latency of the 1800-sweep polar chains of the kappa < 7.27e5 members"}
+    # Members of one engine advance in lock step, so one launch is as long as the slowest member's longest chain: the
+    # members with 1 800-sweep polar rows get an engine of their own, run BESIDE the others (ensemble.latency_groups)
+    groups = ensemble.latency_groups(ov[:, 3], nx, ny)
+    engines = [engine.Engine(inp, p, n_members=len(g), overrides=as_dicts(ov[g]), device=device, strict=strict) for g in groups]
+    ensemble.run_beside([lambda e=e: e.flux_correction(1) for e in engines])
+    bufs = [torch.empty((len(g), 1, 12, 5, engines[0].np), dtype=torch.float32, device="cuda") for g in groups]
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    ensemble.run_beside([lambda e=e, b=b: e.run(1, 680.0, monthly_dev_ptr=b.data_ptr()) for e, b in zip(engines, bufs)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    ok = all(bool(torch.isfinite(b).all().item()) for b in bufs)
+    for e in engines:
+        e.close()
+    del bufs, engines
+    gc.collect(); torch.cuda.empty_cache()
+    out["config5_64_members"] = {"member_years_per_s": round(64 / dt, 2), "finite": ok, "members_with_1800_sweep_polar_rows": int(slow.sum()),
+                                 "engines": [int(len(g)) for g in groups],
+                                 "bound": "latency of the 1800-sweep polar chains of the kappa < 7.27e5 members (their own engine, "
+                                          "run beside the engine of the other members)"}
     keep = ov[~slow]
     r, dt, ok = year_rate(len(keep), as_dicts(keep))
     out["config5_without_those_members"] = {"members": int(len(keep)), "member_years_per_s": round(r, 2), "finite": ok,

@@ -43,6 +43,64 @@ def perturbed_physics(n_members: int, params, seed: int = 20261004, spread: floa
     return (base[None] * (1.0 - spread + 2.0 * spread * u)).astype(np.float32)
 
 
+def max_chain_sweeps(kappa: float, nx: int, ny: int, dt_crcl: float = 1800.0, pi: float = 3.1416) -> int:
+    """The largest number of DEPENDENT zonal diffusion sweeps any latitude row needs per diffusion call for this
+    diffusivity (src/greb.f90:578-580, 652-653, in fp32 as the reference evaluates it; dtdff2 == 0 is the polar-row case
+    SURVEY.md App. B describes: one sweep).  It is what a member costs in latency: 8 at 96x48, 225 at 384x192 -- and
+    1 800 at 384x192 once kappa falls below 7.27e5."""
+    f = np.float32
+    dtc, kap = f(dt_crcl), f(kappa)
+    deg = f(2.0) * f(pi) * f(6.371e6) / f(360.0)
+    dlon, dlat = f(360.0) / f(nx), f(180.0) / f(ny)
+    nint = lambda x: int(np.floor(abs(float(x)) + 0.5) * (1 if x >= 0 else -1))
+    worst = 1
+    for k in range(ny):
+        lat = dlat * f(k + 1) - dlat / f(2.0) - f(90.0)
+        dxlat = dlon * deg * f(np.cos(np.float32(f(2.0) * f(pi) / f(360.0) * lat)))
+        if dxlat > f(2.5e5):
+            continue  # full-row branch: no sub-cycling (:592)
+        dd = max(1, nint(dtc / (f(1.0) * (dxlat * dxlat) / kap)))
+        dtdff2 = int(dtc / f(dd))
+        worst = max(worst, 1 if dtdff2 == 0 else max(1, nint(dtc / f(dtdff2))))
+    return worst
+
+
+def latency_groups(kappas, nx: int, ny: int, ratio: float = 3.0) -> list:
+    """Member indices grouped by what bounds them.  All members of one engine advance in lock step (one launch per
+    sub-step), so the launch is as long as the slowest member's longest chain; members whose chains are `ratio` times
+    longer than the ensemble's median go into a group of their own, to be run by a second engine BESIDE the first
+    (members are independent: the reference runs every one of them as its own process).  Returns one or two index
+    arrays, the large group first."""
+    sweeps = np.asarray([max_chain_sweeps(float(k), nx, ny) for k in kappas])
+    long_ = sweeps > ratio * np.median(sweeps)
+    if not long_.any() or long_.all():
+        return [np.arange(len(sweeps))]
+    return [np.flatnonzero(~long_), np.flatnonzero(long_)]
+
+
+def run_beside(jobs) -> list:
+    """Run the callables in `jobs` concurrently, one host thread each (the engine calls release the GIL and every engine
+    has its own HIP stream), and return their results in order; the first exception is re-raised."""
+    import threading
+    out, err = [None] * len(jobs), [None] * len(jobs)
+
+    def work(i):
+        try:
+            out[i] = jobs[i]()
+        except BaseException as e:  # noqa: BLE001 -- handed to the caller
+            err[i] = e
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
 def partition(n_members: int, world: int, rank: int) -> np.ndarray:
     """Global member ids owned by `rank`: contiguous blocks, sizes differing by at most one."""
     base, rem = divmod(n_members, world)

@@ -44,3 +44,23 @@ def test_shipped_deal_matches_a_candidate():
     cand = [[(k, int(i)) for k, i in re.findall(r"\{(k\w+),(\d+)\}", r)] for r in rows]
     assert norm == cand
     assert re.search(r"constexpr int kPolarWaveFast = (\d+);\s+#endif", src).group(1) == str(ds.polar_wave(first))
+
+
+def test_latency_groups_of_config5():
+    """ensemble.max_chain_sweeps restates the reference's sub-cycle count (src/greb.f90:652-653; SURVEY.md App. B: 8 at
+    96x48, 225 at 384x192, 1 800 once kappa < 7.27e5 there); latency_groups puts exactly config 5's long-chain members
+    into an engine of their own and leaves ensembles without such members in one piece."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from greb_climate_model_amd import abi, ensemble
+    assert ensemble.max_chain_sweeps(8e5, 96, 48) == 8
+    assert ensemble.max_chain_sweeps(8e5, 384, 192) == 225
+    assert ensemble.max_chain_sweeps(7.2e5, 384, 192) == 1800 and ensemble.max_chain_sweeps(7.3e5, 384, 192) == 225
+    ov = ensemble.perturbed_physics(64, abi.default_params())
+    groups = ensemble.latency_groups(ov[:, 3], 384, 192)
+    assert [len(g) for g in groups] == [62, 2]
+    assert sorted(groups[1]) == sorted(i for i in range(64) if ov[i, 3] < 7.27e5)
+    assert sorted(list(groups[0]) + list(groups[1])) == list(range(64))
+    one = ensemble.latency_groups(ov[:, 3], 96, 48)
+    assert len(one) == 1 and list(one[0]) == list(range(64))
+    assert ensemble.run_beside([lambda: 1, lambda: 2]) == [1, 2]
