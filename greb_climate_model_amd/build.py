@@ -16,8 +16,8 @@ LIB = os.path.join(PKG, "libgreb_hip.so")
 # the same sources with -DGREB_TUNING: the timing-experiment knobs of tools/ (GREB_DEBUG_SKIP, GREB_DEBUG_NSUB, ...)
 # exist only in this variant; the release library above never reads the environment
 LIB_TUNING = os.path.join(PKG, "libgreb_hip_tuning.so")
-SOURCES = ["greb_engine.cpp", "greb_kernels.hip", "greb_member.hip", "greb_ensemble.hip", "greb_pair_sweep.hip"]
-HEADERS = ["greb_device.h", "greb_kernels.h", "greb_stencil.h", "greb_pair.h", "greb_physics_step.h", os.path.join(ROOT, "include", "greb_engine.h")]
+SOURCES = ["greb_engine.cpp", "greb_kernels.hip", "greb_member.hip", "greb_ensemble.hip", "greb_pair_sweep.hip", "greb_rows.hip"]
+HEADERS = ["greb_device.h", "greb_kernels.h", "greb_stencil.h", "greb_chain6.h", "greb_pair.h", "greb_physics_step.h", os.path.join(ROOT, "include", "greb_engine.h")]
 # -O2: measured 1.4 % faster than -O3 on the fused member kernel (3 790 vs 3 735 yr/s), equal elsewhere
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                "-I" + os.path.join(ROOT, "include")]
@@ -27,20 +27,44 @@ def hipcc() -> str:
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+# per-source extra flags.  greb_rows.hip: the SLP vectoriser packs the scalar stencil of the row-strip kernel into
+# v_pk_* instructions whose halves it then has to shuffle together (319 v_mov against 113, 156 VGPRs against 120: one
+# wave per SIMD less); a packed fp32 instruction occupies the pipe as long as its two halves would, so nothing is gained.
+EXTRA_FLAGS = {"greb_rows.hip": ["-fno-slp-vectorize"]}
+OBJ_DIR = os.path.join(PKG, "csrc", "_obj")
+
+
+def _deps(src: str) -> list[str]:
+    return [os.path.join(CSRC, src)] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+
+
 def needs_build(lib: str = LIB) -> bool:
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for s in SOURCES for d in _deps(s)) or os.path.getmtime(__file__) > t
 
 
 def build_lib(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+    """One object per source (each with its own flags, rebuilt when the source, a header or this script is newer),
+    then one link.  No relocatable device code is needed: every device function lives in a header."""
     lib = LIB_TUNING if tuning else LIB
     if not force and not needs_build(lib):
         return lib
-    cmd = [hipcc(), *HIPCC_FLAGS, *(["-DGREB_TUNING"] if tuning else []), "-o", lib,
-           *[os.path.join(CSRC, s) for s in SOURCES]]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DGREB_TUNING"] if tuning else [])
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ("_tuning.o" if tuning else ".o"))
+        objs.append(obj)
+        newest = max(max(os.path.getmtime(d) for d in _deps(src)), os.path.getmtime(__file__))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
+            continue
+        cmd = [hipcc(), *flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

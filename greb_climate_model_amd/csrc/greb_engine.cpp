@@ -637,7 +637,7 @@ int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, 
     tab_dev = ce.dev;
   }
   for (int i = 0; i < sweeps; ++i)
-    HIP_TRY0(launch_diffusion(T1_dev, wz_dev, dX_dev, tab_dev, nx, ny, batch, strict != 0, (hipStream_t)stream));
+    HIP_TRY0(launch_diffusion(T1_dev, wz_dev, dX_dev, tab_dev, t, nx, ny, batch, strict != 0, (hipStream_t)stream));
   return 0;
 }
 

@@ -69,8 +69,14 @@ hipError_t launch_circulation_g96(const float* X, const float* wz, const float* 
                                   const RowTables* tab_dev, int batch, int nsub, bool strict, hipStream_t s);
 
 // batched single-routine kernels, any grid with nx % 4 == 0, ny <= kMaxNy
-hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const RowTables* tab_dev, int nx,
-                            int ny, int batch, bool strict, hipStream_t s);
+// tab_host: the same table on the host (the 384-wide row-strip kernel takes its row constants by value)
+hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const RowTables* tab_dev,
+                            const RowTables& tab_host, int nx, int ny, int batch, bool strict, hipStream_t s);
+// greb_rows.hip: the diffusion sweep of a 384-wide grid as wavefront-sized row strips (FAST and STRICT)
+bool rows_supported(const RowTables& t, int nx, int ny);
+bool rows_plan(const RowTables& t, int ny, int target_cost, int& n_strips, int* k0, int* k1);
+hipError_t launch_diffusion_rows(const float* T1, const float* wz, float* dX, const RowTables& t, int ny, int batch,
+                                 bool strict, hipStream_t s);
 hipError_t launch_advection(const float* T1, const float* wz, const float* u, const float* v, float* dX,
                             const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s);
 // 24 sub-steps; 96x48 uses the fused LDS loop of the engine, other grids launch per sub-step

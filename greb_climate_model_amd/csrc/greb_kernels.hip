@@ -295,8 +295,10 @@ static hipError_t launch_sweep(const float* T1, const float* wz, const float* u,
   return hipGetLastError();
 }
 
-hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const RowTables* tab_dev, int nx,
-                            int ny, int batch, bool strict, hipStream_t s) {
+hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const RowTables* tab_dev,
+                            const RowTables& tab_host, int nx, int ny, int batch, bool strict, hipStream_t s) {
+  static const bool no_rows = tuning_int("GREB_NO_ROWS", 0) != 0; // -DGREB_TUNING builds only (A/B experiments)
+  if (!no_rows && rows_supported(tab_host, nx, ny)) return launch_diffusion_rows(T1, wz, dX, tab_host, ny, batch, strict, s);
   static const bool no_stream = tuning_int("GREB_NO_STREAM", 0) != 0; // -DGREB_TUNING builds only (A/B experiments)
   if (stream_fits(nx, ny) && !no_stream) {
     const size_t lds = stream_lds_bytes(nx, ny);
@@ -343,7 +345,7 @@ hipError_t launch_circulation(const float* X, const float* wz, const float* u, c
   hipError_t e = hipMemcpyAsync(Xc, X, n * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return e;
   for (int tt = 0; tt < nsub; ++tt) {
-    if ((e = launch_diffusion(Xc, wz, dd, tab_dev, nx, ny, batch, strict, s)) != hipSuccess) return e;
+    if ((e = launch_diffusion(Xc, wz, dd, tab_dev, tab_host, nx, ny, batch, strict, s)) != hipSuccess) return e;
     if ((e = launch_advection(Xc, wz, u, v, da, tab_dev, nx, ny, batch, strict, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(axpy2_kernel, dim3(1024), dim3(256), 0, s, Xc, dd, da, n);
   }

@@ -244,20 +244,11 @@ __device__ __forceinline__ float wave_from_next(float x) { // lane l <- lane l+1
 }
 
 constexpr int kChainPrioSweeps = 32;
+// the chain on a register window: T[0..P+5] / w[0..P+5] = the lane's P points with three halo points on either side,
+// u[0..P-1] the zonal wind of its points; the result (T1h) is left in T[3..P+2]
 template <bool STRICT, int P>
-__device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfloat* urow, float cc, int time2,
-                               bool is_adv, int lane, lfloat* bufA) {
-  constexpr int NXR = 64 * P, W = P + 6;
-  float T[W], w[W], u[P];
-#pragma unroll
-  for (int i = 0; i < W; ++i) {
-    int j = P * lane - 3 + i;
-    j = j < 0 ? j + NXR : (j >= NXR ? j - NXR : j);
-    w[i] = wrow[j];
-    T[i] = Trow[j];
-  }
-#pragma unroll
-  for (int i = 0; i < P; ++i) u[i] = is_adv ? urow[P * lane + i] : 0.f;
+__device__ __forceinline__ void chain_window(float (&T)[P + 6], const float (&w)[P + 6], const float (&u)[P], float cc,
+                                             int time2, bool is_adv, int lane) {
   const bool bug_lane = lane == 63; // its point P-3 is longitude xdim-2 (1-based), src/greb.f90:881
   // the long chains set the length of the launch: they issue ahead of whatever shares their SIMD (measured 39.0 ->
   // 37.8 us per sub-step launch for one member)
@@ -316,6 +307,22 @@ __device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfl
     for (int i = 0; i < 6; ++i) T[3 + i] = own[i];
   }
   if (time2 >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
+}
+template <bool STRICT, int P>
+__device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfloat* urow, float cc, int time2,
+                               bool is_adv, int lane, lfloat* bufA) {
+  constexpr int NXR = 64 * P, W = P + 6;
+  float T[W], w[W], u[P];
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    int j = P * lane - 3 + i;
+    j = j < 0 ? j + NXR : (j >= NXR ? j - NXR : j);
+    w[i] = wrow[j];
+    T[i] = Trow[j];
+  }
+#pragma unroll
+  for (int i = 0; i < P; ++i) u[i] = is_adv ? urow[P * lane + i] : 0.f;
+  chain_window<STRICT, P>(T, w, u, cc, time2, is_adv, lane);
 #pragma unroll
   for (int i = 0; i < P; ++i) bufA[P * lane + i] = T[3 + i];
   wave_lds_sync();
