@@ -600,6 +600,7 @@ int greb_tuning_set_stamps(greb_engine* e, unsigned long long* stamps_dev) {
 #endif
 
 int greb_release_caches(void) {
+  rows_release_cache();
   std::lock_guard<std::mutex> lock(g_tab_cache.mu);
   int prev = 0;
   const bool have_prev = hipGetDevice(&prev) == hipSuccess;
@@ -639,6 +640,22 @@ int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, 
   for (int i = 0; i < sweeps; ++i)
     HIP_TRY0(launch_diffusion(T1_dev, wz_dev, dX_dev, tab_dev, t, nx, ny, batch, strict != 0, (hipStream_t)stream));
   return 0;
+}
+
+int greb_diffusion_launch_order(const greb_params* p, int nx, int ny, int batch, int* field, int* k0, int* k1, int* up,
+                                int capacity) {
+  if (!p || nx < 12 || (nx & 3) || ny < 5 || ny > kMaxNy || batch < 1 || capacity < 0 ||
+      (capacity > 0 && (!field || !k0 || !k1 || !up)))
+    return fail(nullptr, GREB_E_INVALID, "diffusion_launch_order: bad argument");
+  RowTables t; compute_row_tables(*p, p->kappa, nx, ny, t);
+  if (!rows_supported(t, nx, ny)) return 0;
+  std::vector<RowsTask> tasks;
+  rows_tasks(t, ny, batch, rows_default_tuning(), tasks);
+  for (size_t i = 0; i < tasks.size() && (int)i < capacity; ++i) {
+    field[i] = tasks[i].field; k0[i] = tasks[i].rows & 0xff; k1[i] = (tasks[i].rows >> 8) & 0x1ff;
+    up[i] = (tasks[i].rows & kRowsUp) != 0;
+  }
+  return (int)tasks.size();
 }
 
 int greb_diffusion_batched(const greb_params* p, int nx, int ny, int batch, const float* T1, const float* wz,

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <vector>
 
 #include "greb_device.h"
 
@@ -74,7 +75,20 @@ hipError_t launch_diffusion(const float* T1, const float* wz, float* dX, const R
                             const RowTables& tab_host, int nx, int ny, int batch, bool strict, hipStream_t s);
 // greb_rows.hip: the diffusion sweep of a 384-wide grid as wavefront-sized row strips (FAST and STRICT)
 bool rows_supported(const RowTables& t, int nx, int ny);
-bool rows_plan(const RowTables& t, int ny, int target_cost, int& n_strips, int* k0, int* k1);
+struct RowsTask { int field, rows; }; // rows = k0 | k1 << 8 | kRowsUp: the task updates rows [k0, k1); field < 0: no task
+constexpr int kRowsUp = 1 << 20;       // the strip walks south to north (else north to south)
+struct RowsTuning {
+  int chain_target;    // instructions per chain strip
+  int chain_span;      // per cent of the launch over which the chain strips are spread
+  int parts[4];        // strips the streaming region of a field is cut into, level 0 (most fields) .. 3 (the last fields)
+  int level_tasks[4];  // about how many tasks levels 1..3 hold ([0] unused)
+};
+// measured on MI355X, batch 1 024 (tools/rows_ab.sh; settled clocks): streaming cut 4 / 5 / 6 / 8 / 12 strips per field
+// 0.1738 / 0.1707 / 0.1697 / 0.1685 / 0.1678 ms per launch; chain span 50 / 60 / 70 / 80 / 100 %: 0.1724 / 0.1717 / 0.1691 /
+// 0.181 / 0.209; without the fine levels 0.1724 against 0.1691
+inline RowsTuning rows_default_tuning() { return RowsTuning{3000, 70, {8, 8, 16, 39}, {0, 0, 2048, 1024}}; }
+void rows_tasks(const RowTables& t, int ny, int batch, const RowsTuning& tu, std::vector<RowsTask>& tasks);
+void rows_release_cache();
 hipError_t launch_diffusion_rows(const float* T1, const float* wz, float* dX, const RowTables& t, int ny, int batch,
                                  bool strict, hipStream_t s);
 hipError_t launch_advection(const float* T1, const float* wz, const float* u, const float* v, float* dX,

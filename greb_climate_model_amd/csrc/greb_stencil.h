@@ -248,11 +248,11 @@ constexpr int kChainPrioSweeps = 32;
 // u[0..P-1] the zonal wind of its points; the result (T1h) is left in T[3..P+2]
 template <bool STRICT, int P>
 __device__ __forceinline__ void chain_window(float (&T)[P + 6], const float (&w)[P + 6], const float (&u)[P], float cc,
-                                             int time2, bool is_adv, int lane) {
+                                             int time2, bool is_adv, int lane, bool prio = true) {
   const bool bug_lane = lane == 63; // its point P-3 is longitude xdim-2 (1-based), src/greb.f90:881
   // the long chains set the length of the launch: they issue ahead of whatever shares their SIMD (measured 39.0 ->
   // 37.8 us per sub-step launch for one member)
-  if (time2 >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(3);
+  if (prio && time2 >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(3);
   float K[P][6]; // FAST: d(c) = sum_m K[c][m] * e[c-3+m]
   if (!STRICT) {
     const float cs = cc * 0.05f;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void chain_window(float (&T)[P + 6], const float (&w)
 #pragma unroll
     for (int i = 0; i < 6; ++i) T[3 + i] = own[i];
   }
-  if (time2 >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
+  if (prio && time2 >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(0);
 }
 template <bool STRICT, int P>
 __device__ void chain_lon_regs(const lfloat* Trow, const lfloat* wrow, const lfloat* urow, float cc, int time2,

@@ -54,7 +54,7 @@ EXPORTS = ["greb_params_default", "greb_engine_create", "greb_engine_flux_correc
            "greb_engine_last_error", "greb_engine_destroy", "greb_device_info", "greb_diffusion_batched",
            "greb_advection_batched", "greb_circulation_batched", "greb_diffusion_batched_dev",
            "greb_engine_point_physics", "greb_log_exp_switches", "greb_engine_set_experiment",
-           "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev", "greb_engine_set_state", "greb_release_caches"]
+           "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev", "greb_engine_set_state", "greb_release_caches", "greb_diffusion_launch_order"]
 
 
 def _check(rc: int, h=None):
@@ -202,6 +202,21 @@ def advection(T1, wz, u, v, params=None, strict=False, device=0):
 def circulation(X, wz, u, v, params=None, strict=False, device=0):
     """Batched mirror of circulation(X_in,dX,h_scl,wz), src/greb.f90:528-553."""
     return _batched("greb_circulation_batched", params, (X, wz, u, v), strict, device)
+
+
+def diffusion_launch_order(params, nx, ny, batch):
+    """Host-only diagnostic: the task list of the 384-wide diffusion sweep, arrays (field, k0, k1, up); empty when the
+    grid does not take that kernel (include/greb_engine.h: greb_diffusion_launch_order)."""
+    params = params if params is not None else params_default()
+    f = lib().greb_diffusion_launch_order
+    n = f(C.byref(params), nx, ny, batch, None, None, None, None, 0)
+    if n < 0:
+        _check(n)
+    out = [np.zeros(n, np.int32) for _ in range(4)]
+    if n:
+        ptr = [a.ctypes.data_as(C.POINTER(C.c_int)) for a in out]
+        assert f(C.byref(params), nx, ny, batch, *ptr, n) == n
+    return out
 
 
 def diffusion_dev(params, nx, ny, batch, T1_ptr, wz_ptr, dX_ptr, strict=False, sweeps=1, stream=0):

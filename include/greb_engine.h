@@ -170,9 +170,18 @@ int greb_circulation_batched(const greb_params* p, int nx, int ny, int batch, co
 int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, const float* T1_dev,
                                const float* wz_dev, float* dX_dev, int strict, int sweeps,
                                void* stream);
-/* greb_diffusion_batched_dev keeps one small row-constant table per device between calls (so that back-to-back
- * sweeps are not separated by an allocation); a long-lived host releases them with this.  Engines are unaffected. */
+/* greb_diffusion_batched_dev keeps small immutable tables per device between calls (row constants, the launch order of
+ * the 384-wide sweep) so that back-to-back sweeps are not separated by an allocation.  A table is never rewritten once
+ * made -- calls on different streams or threads, with different kappa or batch, do not disturb each other -- and a
+ * long-lived host releases them with this (it waits for the device first).  Engines are unaffected. */
 int greb_release_caches(void);
+/* Diagnostic, host only (no GPU call): the launch order of the 384-wide diffusion sweep for a batch of fields, as
+ * greb_diffusion_batched_dev would use it -- task i updates rows [k0[i], k1[i]) of field[i] (field < 0: an empty
+ * slot), walking south to north where up[i] != 0.  Returns the number of tasks (only the first `capacity` are
+ * written), 0 when the grid does not take that kernel, < 0 on a bad argument.  Any order is the same arithmetic;
+ * tests check that every row of every field is written exactly once. */
+int greb_diffusion_launch_order(const greb_params* p, int nx, int ny, int batch, int* field, int* k0, int* k1, int* up,
+                                int capacity);
 
 /* Point physics of one step for a batch of columns sets (tests): SWradiation :367-403,
  * LWradiation :407-434, hydro :438-469, deep_ocean :495-525, seaice :472-492 evaluated by the

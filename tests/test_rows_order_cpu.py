@@ -1,0 +1,46 @@
+"""The launch order of the 384-wide diffusion sweep (greb_rows.hip: rows_tasks) is a SPEED choice -- interleaved chain
+and streaming strips, ever shorter strips for the fields launched last -- but it must be a partition: every latitude
+row of every field is written by exactly one task.  Host-only entry point, no GPU needed."""
+import numpy as np
+import pytest
+
+from greb_climate_model_amd import abi, engine
+
+
+@pytest.mark.parametrize("batch", [1, 2, 7, 8, 9, 37, 1024])
+@pytest.mark.parametrize("kappa", [None, 7.2e5])
+def test_every_row_of_every_field_exactly_once(batch, kappa):
+    p = abi.default_params()
+    if kappa is not None:
+        p.kappa = kappa  # the two polar rows become 1 800-sweep chains: another cut of the caps
+    field, k0, k1, up = engine.diffusion_launch_order(p, 384, 192, batch)
+    assert len(field) % 8 == 0 and len(field) > 0
+    live = field >= 0
+    assert field[live].max() == batch - 1 and (field[~live] == -1).all()
+    cover = np.zeros((batch, 192), np.int32)
+    for f, a, b in zip(field[live], k0[live], k1[live]):
+        assert 0 <= a < b <= 192
+        cover[f, a:b] += 1
+    assert (cover == 1).all()
+    # groups of eight: the same strip of eight consecutive fields (blocks are dealt to the eight XCDs in turn)
+    g = np.arange(len(field)) // 8
+    for arr in (k0, k1, up):
+        assert (arr == arr[g * 8]).all()
+    f0 = field[::8]
+    assert (f0 % 8 == 0).all()
+
+
+def test_last_tasks_are_the_short_streaming_strips():
+    p = abi.default_params()
+    field, k0, k1, up = engine.diffusion_launch_order(p, 384, 192, 1024)
+    rows = (k1 - k0)[field >= 0]
+    assert rows[-512:].max() <= 8 < rows[:2048].max()
+    # neighbouring streaming strips of a field walk away from their common border
+    f = 5
+    mine = sorted((a, b, u) for ff, a, b, u in zip(field, k0, k1, up) if ff == f and b - a > 15)
+    assert len(mine) >= 2 and all(x[2] != y[2] for x, y in zip(mine, mine[1:]))
+
+
+def test_other_grids_keep_the_band_kernel():
+    for nx, ny in ((96, 48), (192, 96)):
+        assert len(engine.diffusion_launch_order(abi.default_params(), nx, ny, 4)[0]) == 0

@@ -17,14 +17,22 @@ wz = 0.3 + 0.7 * torch.rand(n, device="cuda", generator=g)
 dX = torch.empty(n, device="cuda")
 st = torch.cuda.current_stream()
 for strict in (False, True):
-    engine.diffusion_dev(p, nx, ny, batch, T1.data_ptr(), wz.data_ptr(), dX.data_ptr(), strict, 3, st.cuda_stream)
+    # warm-up: after an idle second the first ~10 ms of back-to-back launches run through a power-management transient
+    # (tools/launch_spread.py: launches 10-60 up to 1.35 x the settled time); time the settled state
+    warm = int(os.environ.get("WARM", "150"))
+    engine.diffusion_dev(p, nx, ny, batch, T1.data_ptr(), wz.data_ptr(), dX.data_ptr(), strict, warm, st.cuda_stream)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    engine.diffusion_dev(p, nx, ny, batch, T1.data_ptr(), wz.data_ptr(), dX.data_ptr(), strict, 20, st.cuda_stream)
-    e1.record(st); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
-    print(f"diffusion {nx}x{ny} batch={batch} strict={strict} skip={os.environ.get('GREB_DEBUG_SKIP','0')}: {ms:.4f} ms/sweep -> {12.0*n/ms/1e6:.1f} GB/s algorithmic")
+    reps = []
+    for _ in range(int(os.environ.get("REPS", "5"))):  # each repetition times 20 back-to-back launches
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        engine.diffusion_dev(p, nx, ny, batch, T1.data_ptr(), wz.data_ptr(), dX.data_ptr(), strict, 20, st.cuda_stream)
+        e1.record(st); torch.cuda.synchronize()
+        reps.append(e0.elapsed_time(e1) / 20)
+    ms = float(np.median(reps))
+    if os.environ.get("SHOW_REPS"):
+        print("   reps:", " ".join(f"{r:.4f}" for r in reps))
+    print(f"diffusion {nx}x{ny} batch={batch} strict={strict} skip={os.environ.get('GREB_DEBUG_SKIP','0')}: {ms:.4f} ms/sweep (min {min(reps):.4f} max {max(reps):.4f}) -> {12.0*n/ms/1e6:.1f} GB/s algorithmic")
 a = torch.empty(n, device="cuda")
 for _ in range(3): a.copy_(T1)
 torch.cuda.synchronize()
