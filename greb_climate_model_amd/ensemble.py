@@ -127,6 +127,28 @@ def gather_monthly(local, n_members: int, group=None):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
+def ranks_seen(device="cpu", group=None) -> int:
+    """How many distinct ranks the collective backend really connects: every rank contributes its id to one
+    all_gather (RCCL on the node, gloo in the CPU tests); 1 without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    mine = torch.tensor([dist.get_rank(group)], dtype=torch.int64, device=device)
+    ids = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(ids, mine, group=group)
+    return len({int(t.item()) for t in ids})
+
+
+def gather_order_check(member_values) -> dict:
+    """Are the gathered members in GLOBAL member order?  member_values[g] is a quantity that grows with the member
+    index g -- in a CO2 sweep (co2_sweep) the annual-mean surface temperature of the last year -- so a block that
+    landed in another rank's slot, or members permuted inside a block, show up as inversions."""
+    v = np.asarray(member_values, np.float64)
+    inv = int(np.count_nonzero(np.diff(v) <= 0)) if v.size > 1 else 0
+    return {"gather_verified": bool(inv == 0 and np.isfinite(v).all()), "inversions": inv, "members_checked": int(v.size)}
+
+
 def local_moments(x):
     """Per-element fp64 sum and sum of squares, min and max over this GPU's members: one pass of the HIP kernel
     greb_ensemble_moments_dev over x [m_local, ...] (float32, CUDA, contiguous).  No CPU path."""

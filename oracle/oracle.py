@@ -25,6 +25,8 @@ REF_SO = os.path.join(HERE, "_ref", "libgreb_ref.so")
 REF_BIN = os.path.join(HERE, "_ref", "greb_ref")
 REF384_SO = os.path.join(HERE, "_ref", "libgreb_ref384.so")  # `make ref384`: the reference with xdim = 384, ydim = 192
 REF384_BIN = os.path.join(HERE, "_ref", "greb_ref384")
+REF192_SO = os.path.join(HERE, "_ref", "libgreb_ref192.so")  # `make ref192`: the reference with xdim = 192, ydim = 96
+REF192_BIN = os.path.join(HERE, "_ref", "greb_ref192")
 ORIG_BIN = os.path.join(HERE, "_ref", "greb_orig")  # the upstream variant with the log_exp switches
 NT = 730
 fp = abi.fptr
@@ -206,8 +208,8 @@ class RefLib:
         (src/greb.f90:176-216), which are taken from `oracle` (they are inputs here; the
         preamble itself is pinned by the whole-run comparison)."""
         # the reference's grid is compile-time (src/greb.f90:36): one library per grid
-        assert (inp.nx, inp.ny) in ((96, 48), (384, 192)), "no reference build for this grid"
-        self.lib = L = C.CDLL(REF_SO if inp.nx == 96 else REF384_SO)
+        assert (inp.nx, inp.ny) in ((96, 48), (192, 96), (384, 192)), "no reference build for this grid"
+        self.lib = L = C.CDLL({96: REF_SO, 192: REF192_SO, 384: REF384_SO}[inp.nx])
         self.nx, self.ny, self.np = inp.nx, inp.ny, inp.nx * inp.ny
         self.inp = inp
         self.g2("z_topo")[:] = inp.z_topo

@@ -32,6 +32,22 @@ def test_dry_launch_two_ranks_partition():
     assert [p["rank"] for p in parts] == [0, 1] and [p["local_rank"] for p in parts] == [0, 1]
     assert [(p["first"], p["count"]) for p in parts] == [(0, 6), (6, 6)]  # weak scaling: M members per GPU
     assert parts[0]["co2_first"] == 280.0 and 280.0 < parts[1]["co2_first"] < 1120.0
+    # the toy record went through the timed run's gather path: both ranks seen, every member in its own slot
+    assert out["ranks_seen"] == 2 and out["backend"] == "gloo"
+    assert out["gather_verified"] is True and out["inversions"] == 0 and out["members_checked"] == 12
+
+
+def test_gather_order_check_finds_a_misplaced_block():
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from greb_climate_model_amd import ensemble
+    v = ensemble.co2_sweep(16).astype(np.float64)
+    assert ensemble.gather_order_check(v)["gather_verified"] is True
+    swapped = np.concatenate([v[8:], v[:8]])  # the two ranks' blocks in each other's slots
+    bad = ensemble.gather_order_check(swapped)
+    assert bad["gather_verified"] is False and bad["inversions"] == 1
+    v[3] = np.nan
+    assert ensemble.gather_order_check(v)["gather_verified"] is False
 
 
 def test_gpus_flag_must_match_world_size():

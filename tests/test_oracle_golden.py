@@ -204,3 +204,30 @@ def test_run_g384_first_year_bit_exact(inputs384, oracle_lib):
         assert hashlib.sha256(np.ascontiguousarray(mon[i]).tobytes()).hexdigest() == m["month_sha256"][i], i
     assert np.array_equal(mon[:, :, list(g["rows"])], g["polar_rows"][:12])
     assert np.allclose(np.concatenate([yf, yr]), g["yearly"][:2], rtol=0, atol=6e-4)
+
+
+# ------------------------------------------------------------------------------------ 192x96
+def test_oracle_pinned_at_g192(oracle_lib):
+    """The third grid, pinned like the other two (tests/golden/make_golden_g192.py: the reference compiled with only
+    src/greb.f90:36 changed to xdim = 192, ydim = 96): per routine and for a 1+1-yr run, all twelve months in full."""
+    import hashlib
+    from greb_climate_model_amd import abi, workload
+    m = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))["items"]
+    assert m["routine_g192"]["oracle_bit_identical"] is True and m["g192_short"]["oracle_bit_identical"] is True
+    g, gs = load_golden("routine_g192.npz"), load_golden("g192_short.npz")
+    inp = workload.make_inputs(192, 96)
+    o = oracle_lib.Oracle(inp, abi.default_params(ipx=190, ipy=75))
+    grid = o.grid()
+    assert int(grid["dif_time2"].max()) == 129 and int((grid["dif_time2"] > 1).sum()) == 10 and int(grid["subcycled"].sum()) == 96
+    ityr = m["routine_g192"]["ityr"]
+    for name, X, W in (("Ta", inp.tclim[ityr - 1], o.field(5).copy()), ("q", inp.qclim[ityr - 1], o.field(6).copy())):
+        assert np.array_equal(o.diffusion(X, W), g["dif_" + name])
+        assert np.array_equal(o.advection(X, W, ityr=ityr), g["adv_" + name])
+        assert np.array_equal(o.circulation(X, W, ityr=ityr), g["crc_" + name])
+    yf = o.flux_correction(1)
+    mon, yr = o.run(1, 680.0)
+    o.close()
+    mon = mon.reshape(12, 5, 96, 192)
+    assert np.array_equal(mon, gs["monthly"])
+    assert hashlib.sha256(np.ascontiguousarray(mon).tobytes()).hexdigest() == m["g192_short"]["sha256"]
+    assert np.allclose(np.concatenate([yf, yr]), gs["yearly"], rtol=0, atol=3e-4)

@@ -2,9 +2,10 @@
 """Summary of tools/prof_rows.sh's counter passes for the 384x192 diffusion sweep: per kernel the per-dispatch counter
 means and the figures derived from them by the rules of MI355X_MICROARCH.md (FETCH_SIZE x 2 on gfx950; SQ_* wave
 counters in quad-cycles; GRBM_GUI_ACTIVE summed over the 8 XCDs)."""
-import collections, csv, glob, os, sys
+import collections, csv, glob, json, os, sys
 
 d = sys.argv[1]
+json_out = sys.argv[2] if len(sys.argv) > 2 else None  # record of the FAST row-strip kernel for bench.py's bound string
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(d, "*", "run_counter_collection.csv")):
     per = collections.defaultdict(float)
@@ -48,3 +49,19 @@ for k in sorted(cnt):
         print(f"   LDS bank-conflict cycles {100 * c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1):.1f} % of the LDS-active cycles")
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         print(f"   L2 hit rate              {100 * c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.1f} %")
+    if json_out and "dif_rows_kernel<false" in k and "FETCH_SIZE" in c and "SQ_BUSY_CYCLES" in c:
+        cyc = c["SQ_BUSY_CYCLES"] / 32  # one SQ per shader engine, 32 of them: same pass as the wave counters
+        rec = {"kernel": "greb::dif_rows_kernel<false, 0>",
+               "source": "rocprofv3 --pmc passes (each on its own) on `python tools/microbench_dif.py 1024 384 192`, MI355X, "
+                         "tools/prof_rows.sh; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM); "
+                         "SQ_* wave counters in quad-cycles; SQ_BUSY_CYCLES summed over the 32 shader engines",
+               "batch": 1024, "fetch_size_kb_per_launch": round(c["FETCH_SIZE"]), "write_size_kb_per_launch": round(c["WRITE_SIZE"]),
+               "traffic_bytes_per_launch": round((c["FETCH_SIZE"] * 2 + c["WRITE_SIZE"]) * 1024),
+               "algorithmic_bytes_per_launch": int(ALGO),
+               "valu_insts_per_field": round(c["SQ_INSTS_VALU"] / 1024),
+               "valu_active_pct": round(100 * c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc), 1),
+               "waves_per_simd": round(c["SQ_WAVE_CYCLES"] * 4 / cyc / 1024, 2),
+               "wave_cycles_issuing_pct": round(100 * c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 1),
+               "wave_cycles_issue_stalled_pct": round(100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 1),
+               "wave_cycles_parked_pct": round(100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 1)}
+        json.dump(rec, open(json_out, "w"), indent=1)
