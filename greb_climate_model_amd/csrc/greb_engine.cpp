@@ -481,6 +481,9 @@ int greb_engine_run(greb_engine* e, int years, const float* co2_ppm, float* mont
       HIP_TRY(e, hipEventRecord(e->ev_free[sl], e->copy_stream));
       return 0;
     };
+    // an error anywhere below must not return while copies into the CALLER's buffer are still in flight (the caller
+    // may free it as soon as it sees the error): the body runs in a lambda and both streams are drained on failure
+    const int rc_years = [&]() -> int {
     for (int y = 0; y < years; ++y) {
       const int sl = y & 1;
       if (y >= 2) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_free[sl], 0)); // slot's previous year has left
@@ -496,6 +499,13 @@ int greb_engine_run(greb_engine* e, int years, const float* co2_ppm, float* mont
     }
     if (int rc = deliver(years - 1)) return rc;
     HIP_TRY(e, hipStreamSynchronize(e->copy_stream));
+    return 0;
+    }();
+    if (rc_years) {
+      (void)hipStreamSynchronize(e->copy_stream);
+      (void)hipStreamSynchronize(e->stream);
+      return rc_years;
+    }
   }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->it_scnr += (long long)years * kNT;
@@ -582,10 +592,14 @@ int batched_common(const greb_params* p, int nx, int ny, int batch, int device) 
 #define HIP_TRY0(expr) HIP_TRY(nullptr, expr)
 
 namespace {
+// device copies of row tables for greb_diffusion_batched_dev: one entry per (device, table contents), IMMUTABLE once
+// uploaded -- a sweep in flight on any stream never sees its table change under it (the upload of a new table goes to
+// a new buffer; the synchronous copy completes before the call that made it launches anything) -- and freed only by
+// greb_release_caches(), which waits for the device first.
 struct TabCache {
-  struct Entry { RowTables* dev = nullptr; RowTables host; bool valid = false; };
+  struct Entry { int device; RowTables* dev; RowTables host; };
   std::mutex mu;
-  std::map<int, Entry> by_device;
+  std::vector<Entry> entries;
 } g_tab_cache;
 } // namespace
 
@@ -604,9 +618,9 @@ int greb_release_caches(void) {
   std::lock_guard<std::mutex> lock(g_tab_cache.mu);
   int prev = 0;
   const bool have_prev = hipGetDevice(&prev) == hipSuccess;
-  for (auto& kv : g_tab_cache.by_device)
-    if (kv.second.dev && hipSetDevice(kv.first) == hipSuccess) (void)hipFree(kv.second.dev);
-  g_tab_cache.by_device.clear();
+  for (auto& e : g_tab_cache.entries)
+    if (e.dev && hipSetDevice(e.device) == hipSuccess) { (void)hipDeviceSynchronize(); (void)hipFree(e.dev); }
+  g_tab_cache.entries.clear();
   if (have_prev) (void)hipSetDevice(prev);
   return 0;
 }
@@ -615,9 +629,9 @@ int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, 
                                const float* wz_dev, float* dX_dev, int strict, int sweeps, void* stream) {
   if (!p || nx < 12 || (nx & 3) || ny < 5 || ny > kMaxNy || batch < 1 || sweeps < 1)
     return fail(nullptr, GREB_E_INVALID, "diffusion_batched_dev: bad argument");
-  // The row table lives in a small device buffer cached PER DEVICE (the launches must not be separated by an
-  // allocation or a copy: this entry point is what the HBM-roofline measurement times).  The operands must live on
-  // the calling thread's current device.
+  // The row table lives in a small device buffer cached per device and table contents (the launches must not be
+  // separated by an allocation or a copy: this entry point is what the HBM-roofline measurement times).  The operands
+  // must live on the calling thread's current device.
   int dev = 0;
   HIP_TRY0(hipGetDevice(&dev));
   hipPointerAttribute_t attr;
@@ -629,13 +643,16 @@ int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, 
   RowTables* tab_dev = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_tab_cache.mu);
-    TabCache::Entry& ce = g_tab_cache.by_device[dev];
-    if (!ce.dev) { HIP_TRY0(dev_alloc(&ce.dev, 1)); ce.valid = false; }
-    if (!ce.valid || std::memcmp(&t, &ce.host, sizeof(t)) != 0) {
-      HIP_TRY0(hipMemcpy(ce.dev, &t, sizeof(t), hipMemcpyHostToDevice));
-      ce.host = t; ce.valid = true;
+    for (const TabCache::Entry& ce : g_tab_cache.entries)
+      if (ce.device == dev && std::memcmp(&t, &ce.host, sizeof(t)) == 0) { tab_dev = ce.dev; break; }
+    if (!tab_dev) {
+      TabCache::Entry ce{dev, nullptr, t};
+      HIP_TRY0(dev_alloc(&ce.dev, 1));
+      hipError_t he = hipMemcpy(ce.dev, &t, sizeof(t), hipMemcpyHostToDevice);
+      if (he != hipSuccess) { (void)hipFree(ce.dev); HIP_TRY0(he); }
+      g_tab_cache.entries.push_back(ce);
+      tab_dev = ce.dev;
     }
-    tab_dev = ce.dev;
   }
   for (int i = 0; i < sweeps; ++i)
     HIP_TRY0(launch_diffusion(T1_dev, wz_dev, dX_dev, tab_dev, t, nx, ny, batch, strict != 0, (hipStream_t)stream));

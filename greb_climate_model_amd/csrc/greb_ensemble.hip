@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/greb_engine.h"
+#include "greb_kernels.h"
 
 namespace {
 
@@ -164,7 +165,7 @@ int greb_ensemble_quantiles_dev(const float* x_dev, int n_members, size_t n, con
 #define GREB_QLAUNCH(PP)                                                                                              \
   {                                                                                                                   \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(quantile_kernel<PP>),                           \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, greb::kMaxDynamicLds);             \
     if (e != hipSuccess) return (int)e;                                                                               \
     hipLaunchKernelGGL(quantile_kernel<PP>, dim3(grid), dim3(kQThreads), lds, s, x_dev, n_members, mpad, n, pr, out_dev); \
   }

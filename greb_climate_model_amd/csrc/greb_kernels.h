@@ -24,6 +24,12 @@ inline int tuning_int(const char* name, int dflt) {
 constexpr int tuning_int(const char*, int dflt) { return dflt; }
 #endif
 
+// Kernels whose dynamic LDS size depends on the call (grid, band size, member count) are all allowed the SAME maximum:
+// the attribute is per kernel, not per launch, and two host threads driving two engines side by side
+// (ensemble.run_beside) must not lower it between each other's set and launch.  What a launch occupies is the size it
+// passes, not this ceiling.
+constexpr int kMaxDynamicLds = 160 * 1024;
+
 // Everything the fused member kernel needs (passed by value as a kernel argument).
 struct MemberArgs {
   int nx, ny, np;

@@ -289,7 +289,7 @@ static hipError_t launch_sweep(const float* T1, const float* wz, const float* u,
   dim3 grid(batch, bands), block(256);
   auto kern = strict ? sweep_kernel<true, MODE> : sweep_kernel<false, MODE>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, block, lds, s, T1, wz, u, v, dX, tab_dev, nx, ny, rows, wmod, uv_shared, tab_index, tab_div, calm_odd);
   return hipGetLastError();

@@ -310,7 +310,7 @@ hipError_t launch_substep_pairs(const float* X2, const float* W2p, const float* 
   if (rows < 1 || rows > kMaxBandRows) return hipErrorInvalidValue;
   const size_t lds = pair_lds_bytes(rows);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_pair_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
   if (e != hipSuccess) return e;
   const int ngroups = (n_members + kPairGroup - 1) / kPairGroup;
   hipLaunchKernelGGL(sweep_pair_kernel, dim3(8 * ((ngroups + 7) / 8) * bands), dim3(kPairThreads), lds, s, X2, W2p, u, v, Xnew2, tabs,

@@ -58,15 +58,38 @@ def rms(a, b):
     return float(np.sqrt(np.mean(d * d)))
 
 
+JDAY_MON = (31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31)  # src/greb.f90:42
+
+
+def global_mean_fp64(monthly_year):
+    """Annual global-mean Tsurf in deg C from one year of monthly means [12][5][ny][nx], summed in fp64: what the
+    console value of src/greb.f90:954 is in exact arithmetic (the monthly records are per-step sums / steps of the
+    month, so the day-weighted mean of the twelve is the mean over the year's 730 steps)."""
+    m = np.asarray(monthly_year, np.float64)[:, 0].reshape(12, -1).mean(axis=1)
+    return float((m * np.asarray(JDAY_MON)).sum() / 365.0 - 273.15)
+
+
+def fast_global_mean_is_the_better_one(yearly_fast, yearly_ref, monthly_year, label=""):
+    """The FAST engine's printed global mean (per-lane partial sums + wavefront shuffle reduction) against the fp64
+    mean of its own monthly output, next to the same distance for the REFERENCE's printed value (a sequential fp32
+    sum): the tolerance yearly_close() grants FAST exists because the reference's number is the noisier one."""
+    exact = global_mean_fp64(monthly_year)
+    d_fast, d_ref = abs(float(yearly_fast) - exact), abs(float(yearly_ref) - exact)
+    print(f"{label} global mean: fp64 of the monthly output {exact:.6f}  FAST console value off by {d_fast:.2e}  reference's off by {d_ref:.2e}")
+    assert d_fast < 2.5e-4, (label, d_fast)
+    return d_fast, d_ref
+
+
 def yearly_close(got, ref, strict=False, npoints=4608):
     """The console values of src/greb.f90:954: [..., 0] = global-mean Tsurf, [..., 1] = Tsurf at (ipx, ipy), deg C.
     The point value is one fp32 number: 1e-4 K = 3 ulp at 285 K.  The global mean is `sum(tsmn)/(xdim*ydim)`, which
     the reference evaluates as a SEQUENTIAL fp32 sum of 4608 (73 728) values of ~280 K: partial sums reach 1.3e6
     (ulp 0.125), so the reference's own printed mean carries a rounding error of a few 1e-4 K.  STRICT arithmetic
     sums in the same order (2e-4: only the libm-level differences of the run remain); FAST sums by per-lane partials
-    + wavefront shuffle reduction, which is closer to the exact mean than the reference's value is -- 1e-3 at
-    96x48; the sequential sum's error grows like sqrt(n) * ulp(sum) / n ~ sqrt(n), so 4e-3 at 384x192."""
+    + wavefront shuffle reduction, which is closer to the exact mean than the reference's value is (shown against an
+    fp64 mean by fast_global_mean_is_the_better_one): 1e-3 at 96x48 (measured 3e-4 ... 7e-4 over 53 years); the
+    sequential sum's error grows with the number of addends, measured 1.3e-3 at 384x192: 2.5e-3 there."""
     d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
     assert d[..., 1].max() < 1e-4, ("point value", d[..., 1].max())
-    tol = 2e-4 if strict else 1e-3 * max(1.0, (npoints / 4608.0) ** 0.5)
+    tol = 2e-4 if strict else 1e-3 * max(1.0, (npoints / 4608.0) ** 0.33)
     assert d[..., 0].max() < tol, ("global mean", d[..., 0].max(), tol)

@@ -16,7 +16,7 @@ import pytest
 
 import os
 
-from conftest import GOLDEN, load_golden, rms, yearly_close
+from conftest import GOLDEN, fast_global_mean_is_the_better_one, load_golden, rms, yearly_close
 
 pytestmark = pytest.mark.gpu
 
@@ -170,6 +170,8 @@ def test_run_short_vs_reference(eng_mod, params, inputs, strict):
     _check_run(mon[0].reshape(24, 5, 48, 96), g["monthly"], "strict" if strict else "fast")
     yearly = np.concatenate([yf[0], yr[0]])
     yearly_close(yearly, g["yearly"], strict)
+    if not strict:
+        fast_global_mean_is_the_better_one(yr[0][1][0], g["yearly"][2][0], mon[0, 1], "96x48 year 2")
     st = e.state(0)
     for i in range(4):
         assert rms(st[i], g["final_state5"][i]) < (1e-3 if i < 3 else 1e-7)
@@ -250,7 +252,7 @@ def _g384_reductions_close(mon, g, label, months=None):
         dz = np.abs(zon[:, i] - g["zonal"][:n, i]).max()
         r = rms(mon[:n, i][:, list(g["rows"])], g["polar_rows"][:n, i])
         print(f"{label:>24s} {name:7s} zonal-mean max diff {dz:.2e}  polar-rows rms {r:.2e} (tol {tol:.0e})")
-        assert dz < 2 * tol and r < 2 * tol, (label, name, dz, r)
+        assert dz < tol and r < tol, (label, name, dz, r)  # worst measured: 0.46 x / 0.22 x tol (profiles/r02_gpu_parity_numbers.txt)
 
 
 @pytest.mark.parametrize("kappa", [None, 7.2e5])
@@ -341,6 +343,8 @@ def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
     _check_run(last[[0, 11, 23]], g["monthly_sel"], f"g384 {mode}")
     _g384_reductions_close(last, g, f"g384 {mode}")
     yearly_close(np.concatenate([yf[-1], yr[-1]]), g["yearly"], mode == "strict", 384 * 192)
+    if mode != "strict":
+        fast_global_mean_is_the_better_one(yr[-1][1][0], g["yearly"][2][0], mon[-1, 1], f"384x192 {mode} year 2")
     assert rms(mon[0, 1, 11, 0], mon[-1, 1, 11, 0]) > 1e-2  # the members differ (CO2)
     if nm > 2:
         assert np.array_equal(mon[0], mon[1])  # replicas agree bit for bit
