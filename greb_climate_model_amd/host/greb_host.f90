@@ -28,6 +28,14 @@
 !   ens_da_ice(:), ens_a_no_ice(:), ens_a_cloud(:), ens_kappa(:)
 !                        per-member values of these &PHYSICS_PAR parameters (BASELINE config 5); unset = the
 !                        &PHYSICS_PAR value.  Members with their own physics get their own flux correction.
+!   n_procs, proc_id     ONE ensemble over SEVERAL host processes (one per GPU: the reference's own convention of N
+!                        processes with N ens_ids, src/greb.f90:153,1064-1068): the namelist describes the whole
+!                        ensemble, process proc_id (0-based) of n_procs integrates its contiguous block of members --
+!                        block sizes differ by at most one, the rule of greb_climate_model_amd/ensemble.py:partition --
+!                        and writes only their <output_file>_<ens_id> files.  Also settable from the command line, so
+!                        that all processes share one namelist file:   greb_host <namelist> <proc_id> <n_procs> [plan]
+!                        (`plan` prints the block and stops before any input is read or any GPU is touched).  With
+!                        &ENGINE_PAR device unset, process proc_id uses GPU proc_id.  tools/launch_ensemble.py starts them.
 ! The interface module is host/greb_c_api.f90.
 
 program greb_host
@@ -62,11 +70,14 @@ program greb_host
   integer :: chunk_years
   namelist / engine_par / strict, device, corr_file, nx, ny, chunk_years
   ! ---- ensemble
-  integer :: n_members
+  integer :: n_members, n_total, n_procs, proc_id, first_member, gm
+  logical :: plan_only
+  character(len=16) :: arg
   character(len=10), allocatable :: ens_ids(:)
   real, allocatable :: co2_levels(:), ens_da_ice(:), ens_a_no_ice(:), ens_a_cloud(:), ens_kappa(:)
   real :: co2_lo, co2_hi
-  namelist / ensemble_par / n_members, ens_ids, co2_levels, co2_lo, co2_hi, ens_da_ice, ens_a_no_ice, ens_a_cloud, ens_kappa
+  namelist / ensemble_par / n_members, ens_ids, co2_levels, co2_lo, co2_hi, ens_da_ice, ens_a_no_ice, ens_a_cloud, ens_kappa, &
+       n_procs, proc_id
   type(greb_member_overrides), allocatable, target :: ov(:)
   real(c_float), allocatable :: co2_all(:)
   integer, allocatable :: units(:)
@@ -100,8 +111,8 @@ program greb_host
   co2_flux = prm%co2_flux
   ipx = 1; ipy = 1; time_flux = 0; time_scnr = 0; year0 = 1940
   output_file = 'output/scenario'; ens_id = ''
-  strict = .false.; device = 0; corr_file = ''; nx = 96; ny = 48; chunk_years = 0
-  n_members = 1; co2_lo = unset; co2_hi = unset
+  strict = .false.; device = -1; corr_file = ''; nx = 96; ny = 48; chunk_years = 0
+  n_members = 1; co2_lo = unset; co2_hi = unset; n_procs = 1; proc_id = 0; plan_only = .false.
   allocate(ens_ids(max_members), co2_levels(max_members), ens_da_ice(max_members), ens_a_no_ice(max_members), &
        ens_a_cloud(max_members), ens_kappa(max_members))
   ens_ids = ''; co2_levels = unset; ens_da_ice = unset; ens_a_no_ice = unset; ens_a_cloud = unset; ens_kappa = unset
@@ -124,6 +135,32 @@ program greb_host
      print*, 'greb_host: n_members must be 1 ..', max_members
      error stop 1
   end if
+  ! ---- this process's block of the ensemble
+  if (nargs >= 3) then
+     call get_command_argument(2, arg); read(arg, *, iostat=ios) proc_id
+     if (ios == 0) then
+        call get_command_argument(3, arg); read(arg, *, iostat=ios) n_procs
+     end if
+     if (ios /= 0) then
+        print*, 'greb_host: usage: greb_host [namelist [proc_id n_procs [plan]]]'
+        error stop 1
+     end if
+  end if
+  if (nargs >= 4) then
+     call get_command_argument(4, arg)
+     plan_only = trim(arg) == 'plan'
+  end if
+  if (n_procs < 1 .or. proc_id < 0 .or. proc_id >= n_procs) then
+     print*, 'greb_host: need 0 <= proc_id < n_procs, got ', proc_id, n_procs
+     error stop 1
+  end if
+  n_total = n_members
+  first_member = proc_id*(n_total/n_procs) + min(proc_id, mod(n_total, n_procs)) + 1
+  n_members = n_total/n_procs
+  if (proc_id < mod(n_total, n_procs)) n_members = n_members + 1
+  if (device < 0) device = merge(proc_id, 0, n_procs > 1)
+  if (n_procs > 1) print '(a,i0,a,i0,a,i0,a,i0,a,i0,a,i0)', ' % ENSEMBLE BLOCK; process ', proc_id, ' of ', n_procs, &
+       ': members ', first_member, ' .. ', first_member + n_members - 1, ' of ', n_total, ' on device ', device
 
   ! a series shorter than the run is continued with its last value; none at all means 2xCO2
   if (co2_ppm(1) == -1.) co2_ppm(1) = 680.
@@ -140,21 +177,38 @@ program greb_host
   print*,'% diagonstic point lat/lon: ',(180./ny)*ipy-90, (360./nx)*ipx
 
   ! ---- the ensemble: ids, CO2 series [years, member] and physics overrides per member
-  do m = 1, n_members
+  do m = 1, n_total
      if (len_trim(ens_ids(m)) == 0) then
-        if (n_members == 1) then
+        if (n_total == 1) then
            ens_ids(m) = ens_id
         else
            write(ens_ids(m), '(i3.3)') m
         end if
      end if
   end do
+  ! from here on m = 1 .. n_members counts THIS process's members; member m is member first_member + m - 1 of the ensemble
+  do m = 1, n_members
+     gm = first_member + m - 1
+     ens_ids(m) = ens_ids(gm); co2_levels(m) = co2_levels(gm)
+     ens_da_ice(m) = ens_da_ice(gm); ens_a_no_ice(m) = ens_a_no_ice(gm); ens_a_cloud(m) = ens_a_cloud(gm); ens_kappa(m) = ens_kappa(gm)
+  end do
+  if (plan_only) then
+     do m = 1, n_members
+        print '(a,i0,a,a)', ' % member ', first_member + m - 1, ' ens_id ', trim(ens_ids(m))
+     end do
+     stop
+  end if
+  if (n_members == 0) then
+     print*, '% no member of the ensemble falls to this process'
+     stop
+  end if
   allocate(co2_all(max(time_scnr,1)*n_members))
   do m = 1, n_members
+     gm = first_member + m - 1
      do i = 1, time_scnr
         co2_all((m-1)*time_scnr + i) = co2_ppm(i)
-        if (co2_lo /= unset .and. co2_hi /= unset .and. n_members > 1) &
-             co2_all((m-1)*time_scnr + i) = real(dble(co2_lo) + dble(co2_hi - co2_lo)*dble(m-1)/dble(n_members-1))
+        if (co2_lo /= unset .and. co2_hi /= unset .and. n_total > 1) &
+             co2_all((m-1)*time_scnr + i) = real(dble(co2_lo) + dble(co2_hi - co2_lo)*dble(gm-1)/dble(n_total-1))
         if (co2_levels(m) /= unset) co2_all((m-1)*time_scnr + i) = co2_levels(m)
      end do
   end do
@@ -259,8 +313,8 @@ program greb_host
   end if
 
   print*,'% MODEL RUN; years = ', time_scnr
-  if (n_members == 1) print*,'% saving output in file ', out_full
-  if (n_members > 1) print*,'% saving output in files ', trim(output_file), '_<ens_id>; members = ', n_members
+  if (n_total == 1) print*,'% saving output in file ', out_full
+  if (n_total > 1) print*,'% saving output in files ', trim(output_file), '_<ens_id>; members = ', n_members
   if (time_scnr > 0) then
      ! the engine's clock continues across calls (include/greb_engine.h), so a long run is taken in chunks of whole
      ! years that keep the monthly-mean buffer [member][year][12][5][ny][nx] below ~2 GB
@@ -269,7 +323,7 @@ program greb_host
      if (chunk_years > 0) chunk = min(chunk_years, time_scnr)   ! &ENGINE_PAR chunk_years: a smaller host buffer
      allocate(monthly(rec_year*chunk*n_members), yearly(2*time_scnr*n_members), units(n_members))
      do m = 1, n_members
-        if (n_members == 1) then
+        if (n_total == 1) then
            open(newunit=units(m), file=out_full, access='direct', form='unformatted', recl=4*nx*ny)
         else
            open(newunit=units(m), file=trim(output_file)//'_'//trim(ens_ids(m)), access='direct', form='unformatted', recl=4*nx*ny)
@@ -289,7 +343,7 @@ program greb_host
      end do
      do m = 1, n_members
         close(units(m))
-        if (n_members > 1) print*, '% MEMBER ', trim(ens_ids(m))
+        if (n_total > 1) print*, '% MEMBER ', trim(ens_ids(m))
         print *, 'console output: year, co2, global avg temp, avg temp for ipx/ipy'
         year = year0
         do n = 1, time_scnr

@@ -225,3 +225,36 @@ def test_host_ensemble_chunked_run_is_identical(tmp_path, inputs):
     assert res[0][1] == res[1][1] and len(res[0][1]) == 1 + 3 * 3
     co2 = [float(r_[1]) for r_ in res[0][1][1:]]
     assert co2 == [400.0, 500.0, 600.0, 700.0, 700.0, 700.0, 400.0, 500.0, 600.0]  # member 2 at its constant level
+
+
+def test_host_ensemble_split_over_processes(tmp_path, inputs):
+    """ONE ensemble over SEVERAL host processes through the drop-in boundary (greb_host <namelist> <proc_id> <n_procs>,
+    tools/launch_ensemble.py): an 8-member CO2 sweep as one process, then as blocks 0 and 1 of two processes run one
+    after the other on device 0 -- the per-ens_id files must be identical bit for bit (members do not interact, and the
+    shared flux correction is recomputed identically by each process), and so must every member's console trace."""
+    import sys
+    from greb_climate_model_amd import build, workload
+    host = _need(os.path.join(build.PKG, "greb_host"))
+    inputs.write_input_dir(str(tmp_path / "input"))
+    os.makedirs(tmp_path / "output")
+    ens = "&ENGINE_PAR\n  device = 0\n/\n&ENSEMBLE_PAR\n  n_members = 8\n  co2_lo = 280.\n  co2_hi = 1120.\n/\n"
+    workload.write_namelist(str(tmp_path / "namelist"), 1, 2, (680.0,), 95, 38, output_file="output/one")
+    with open(tmp_path / "namelist", "a") as f:
+        f.write(ens)
+    r = subprocess.run([host], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows_one = [l.split() for l in r.stdout.splitlines() if len(l.split()) == 4 and l.split()[0][0].isdigit()]
+    workload.write_namelist(str(tmp_path / "namelist"), 1, 2, (680.0,), 95, 38, output_file="output/two")
+    with open(tmp_path / "namelist", "a") as f:
+        f.write(ens)
+    launcher = os.path.join(os.path.dirname(build.PKG), "tools", "launch_ensemble.py")
+    r2 = subprocess.run([sys.executable, launcher, "--procs", "2", "--serial"], cwd=tmp_path, capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert "process 0 of 2: members 1 .. 4 of 8" in r2.stdout and "process 1 of 2: members 5 .. 8 of 8" in r2.stdout
+    for m in range(1, 9):
+        a = np.fromfile(tmp_path / "output" / f"one_{m:03d}", dtype="<f4")
+        b = np.fromfile(tmp_path / "output" / f"two_{m:03d}", dtype="<f4")
+        assert a.size == 96 * 48 * 5 * 24 and np.array_equal(a, b), m
+    rows_two = [l.split()[1:] for l in r2.stdout.splitlines() if len(l.split()) == 5 and l.split()[1][0].isdigit()]
+    # one flux-correction line per process, then the members' years in global order
+    assert rows_two[0] == rows_one[0] and [x for x in rows_two if x[0] != "0.00000000"] == [x for x in rows_one if x[0] != "0.00000000"], (rows_one[:3], rows_two[:3])
