@@ -10,6 +10,7 @@ NSTEP_YR = 730
 NVAR_OUT = 5
 F_STRICT = 1
 F_MULTILAUNCH = 2
+F_ROW_STRIPS = 4
 RUN_DEVICE_OUT = 1
 # sensitivity-experiment switches, GREB_X_* of include/greb_engine.h
 X_NO_ICE, X_NO_HYDRO, X_NO_DEEP_OCEAN, X_LW_LINEAR_VAPOR = 1, 2, 4, 8

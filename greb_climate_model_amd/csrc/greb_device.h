@@ -189,40 +189,44 @@ __device__ __forceinline__ void clamp_add(E T1h[4], E d[4]) {
   }
 }
 
-// latitudinal diffusion (:585-590).  Tm/Tp, wm/wp: rows k-1 / k+1 (ignored where absent)
+// latitudinal diffusion (:585-590) of one point.  tm/tp, wm/wp: rows k-1 / k+1 (ignored where absent)
+template <typename E>
+__device__ __forceinline__ E dif_lat_point_strict(E t0, E tm, E tp, E wm, E wp, float ccy, int k, int ny) {
+#pragma clang fp contract(off)
+  if (k >= 1 && k <= ny - 2) return ccy * (wm * (tm - t0) + wp * (tp - t0));
+  if (k == 0) return ccy * wp * (-t0 + tp);
+  return ccy * wm * (tm - t0);
+}
 template <typename Q, typename E>
 __device__ __forceinline__ void dif_lat_strict(const Q& T0, const Q& Tm, const Q& Tp, const Q& wm,
                                                const Q& wp, float ccy, int k, int ny, E d[4]) {
-#pragma clang fp contract(off)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (k >= 1 && k <= ny - 2) d[i] = ccy * (wm.v[i] * (Tm.v[i] - T0.v[i]) + wp.v[i] * (Tp.v[i] - T0.v[i]));
-    else if (k == 0) d[i] = ccy * wp.v[i] * (-T0.v[i] + Tp.v[i]);
-    else d[i] = ccy * wm.v[i] * (Tm.v[i] - T0.v[i]);
-  }
+  for (int i = 0; i < 4; ++i) d[i] = dif_lat_point_strict<E>(T0.v[i], Tm.v[i], Tp.v[i], wm.v[i], wp.v[i], ccy, k, ny);
 }
 
-// latitudinal advection (:756-795).  T/w at rows k-2,k-1,k+1,k+2
+// latitudinal advection (:756-795) of one point.  T/w at rows k-2,k-1,k+1,k+2
+template <typename E>
+__device__ __forceinline__ E adv_lat_point_strict(E t0, E tm2, E tm1, E tp1, E tp2, E wm2, E wm1, E wp1, E wp2, float v,
+                                                  float ccy, int k, int ny) {
+#pragma clang fp contract(off)
+  const float vm = split_m(v), vp = split_p(v);
+  const E dm1 = wm1 * (t0 - tm1), dm2 = wm2 * (t0 - tm2);
+  const E dp1 = wp1 * (t0 - tp1), dp2 = wp2 * (t0 - tp2);
+  if (k == 0) return div3(ccy * (vp * (dp1 + dp2)));                              // :759-761
+  if (k == 1) return ccy * (-vm * (dm1) + div3(vp * (dp1 + dp2)));               // :766-769
+  if (k <= ny - 3) return div3(ccy * (-vm * (dm1 + dm2) + vp * (dp1 + dp2)));    // :774-778
+  if (k == ny - 2) return ccy * (div3(-vm * (dm1 + dm2)) + vp * (dp1));          // :784-787
+  return div3(ccy * (-vm * (dm1 + dm2)));                                        // :792-794
+}
 template <typename Q, typename E>
 __device__ __forceinline__ void adv_lat_strict(const Q& T0, const Q& Tm2, const Q& Tm1, const Q& Tp1,
                                                const Q& Tp2, const Q& wm2, const Q& wm1, const Q& wp1,
                                                const Q& wp2, const float v[4], float ccy, int k, int ny,
                                                E d[4]) {
-#pragma clang fp contract(off)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const E t0 = T0.v[i];
-    const float vm = split_m(v[i]), vp = split_p(v[i]);
-    const E dm1 = wm1.v[i] * (t0 - Tm1.v[i]), dm2 = wm2.v[i] * (t0 - Tm2.v[i]);
-    const E dp1 = wp1.v[i] * (t0 - Tp1.v[i]), dp2 = wp2.v[i] * (t0 - Tp2.v[i]);
-    E r;
-    if (k == 0) r = div3(ccy * (vp * (dp1 + dp2)));                              // :759-761
-    else if (k == 1) r = ccy * (-vm * (dm1) + div3(vp * (dp1 + dp2)));           // :766-769
-    else if (k <= ny - 3) r = div3(ccy * (-vm * (dm1 + dm2) + vp * (dp1 + dp2))); // :774-778
-    else if (k == ny - 2) r = ccy * (div3(-vm * (dm1 + dm2)) + vp * (dp1));      // :784-787
-    else r = div3(ccy * (-vm * (dm1 + dm2)));                                    // :792-794
-    d[i] = r;
-  }
+  for (int i = 0; i < 4; ++i)
+    d[i] = adv_lat_point_strict<E>(T0.v[i], Tm2.v[i], Tm1.v[i], Tp1.v[i], Tp2.v[i], wm2.v[i], wm1.v[i], wp1.v[i], wp2.v[i],
+                                   v[i], ccy, k, ny);
 }
 
 // ============================================================================================

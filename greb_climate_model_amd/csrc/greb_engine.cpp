@@ -128,6 +128,10 @@ struct greb_engine {
   float* yearly_dev = nullptr; size_t yearly_cap = 0;
   // host copies needed later
   std::vector<RowTables> h_tabs;
+  std::vector<int> h_tab_index;
+  bool step_rows = false;                                   // 384-wide grid: the row-strip sub-step (greb_step_rows.hip)
+  bool step_rows_always = false;                            // GREB_F_ROW_STRIPS
+  std::map<int, std::pair<RowsTask*, int>> step_tasks;      // its launch order, per number of members run
   std::vector<Phys> h_phys;
   // model clock
   long long it_flux = 0; // steps done in the flux phase
@@ -192,7 +196,23 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
   // smaller, is a little ahead (us per launch, scalar / pairs: 8 members 28.8 / 30.8, 24: 30.3 / 32.4); from ~28
   // members on the pair kernel's packed single-sweep rows win (32: 38.0 / 33.4, 40: 45.5 / 35.4, 62: 68.0 / 52.6).
   static const int pair_min = tuning_int("GREB_PAIR_MIN", 28); // -DGREB_TUNING builds only
-  const bool pairs = e->pairs && nrun >= pair_min && !(e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY);
+  // the row-strip sub-step (greb_step_rows.hip) is the faster form for a few FAST members, whose launch is as long as
+  // one polar chain (us per launch, strips / bands: 1 member 24.0 / 25.1, 4: 28.1 / 28.4, 16: 29.6 / 29.4, 24: 33.7 / 30.5,
+  // 62: 65.8 / 48.0; STRICT 1 member 73.6 / 64.7)
+  static const int rows_max = tuning_int("GREB_STEP_ROWS_MAX", 8); // -DGREB_TUNING builds only
+  const bool rows = e->step_rows && (e->step_rows_always || (!e->strict && nrun <= rows_max));
+  const RowsTask* step_tasks = nullptr;
+  int n_step_tasks = 0;
+  if (rows) {
+    auto it = e->step_tasks.find(nrun);
+    if (it == e->step_tasks.end()) {
+      RowsTask* dev = nullptr; int n = 0;
+      HIP_TRY(e, step_rows_make_tasks(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, &dev, &n));
+      it = e->step_tasks.emplace(nrun, std::make_pair(dev, n)).first;
+    }
+    step_tasks = it->second.first; n_step_tasks = it->second.second;
+  }
+  const bool pairs = !rows && e->pairs && nrun >= pair_min && !(e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY);
   if (pairs) HIP_TRY(e, launch_pack_pairs(e->state, e->Xa, e->np, nrun, e->stream));
   else HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
   for (int s = 0; s < kNT; ++s) {
@@ -201,7 +221,10 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     const size_t off = (size_t)(ityr - 1) * np;
     float *cur = e->Xa, *nxt = e->Xb;
     for (int tt = 0; tt < a.nsub; ++tt) {
-      if (pairs)
+      if (rows)
+        HIP_TRY(e, launch_substep_rows(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, step_tasks,
+                                       n_step_tasks, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
+      else if (pairs)
         HIP_TRY(e, launch_substep_pairs(cur, e->W2p, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->ny, nrun, e->stream));
       else
         HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
@@ -346,6 +369,7 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
   HIP_TRY(e, hipMemcpy(e->tabs, e->h_tabs.data(), e->h_tabs.size() * sizeof(RowTables), hipMemcpyHostToDevice));
   HIP_TRY(e, dev_alloc(&e->tab_index, nm));
   HIP_TRY(e, hipMemcpy(e->tab_index, tab_index.data(), nm * sizeof(int), hipMemcpyHostToDevice));
+  e->h_tab_index = tab_index;
   HIP_TRY(e, dev_alloc(&e->corr_index, nm));
   HIP_TRY(e, hipMemcpy(e->corr_index, corr_index.data(), nm * sizeof(int), hipMemcpyHostToDevice));
 
@@ -377,6 +401,9 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
     HIP_TRY(e, dev_alloc(&e->W2, 2 * np));
     HIP_TRY(e, hipMemcpy(e->W2, wz_air.data(), np * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->W2 + np, wz_vapor.data(), np * sizeof(float), hipMemcpyHostToDevice));
+    static const bool no_step_rows = tuning_int("GREB_NO_STEP_ROWS", 0) != 0; // -DGREB_TUNING builds only (A/B)
+    e->step_rows = !no_step_rows && step_rows_supported(e->h_tabs.data(), (int)e->h_tabs.size(), nx, ny);
+    e->step_rows_always = (flags & GREB_F_ROW_STRIPS) != 0;
     e->pairs = !e->strict && pair_sweep_supported(nx, ny);
     if (e->pairs) {
       std::vector<float> w2p(2 * np);
@@ -396,6 +423,7 @@ int greb_engine_destroy(greb_engine* e) {
                   e->corr, e->corr_index, e->tab_index, e->tabs, e->phys, e->co2_dev, e->monthly_dev, e->yearly_dev,
                   e->Xa, e->Xb, e->red, e->W2, e->W2p};
   for (void* q : ptrs) if (q) (void)hipFree(q);
+  for (auto& kv : e->step_tasks) if (kv.second.first) (void)hipFree(kv.second.first);
   for (int i = 0; i < 2; ++i) {
     if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
     if (e->ev_free[i]) (void)hipEventDestroy(e->ev_free[i]);
@@ -671,6 +699,22 @@ int greb_diffusion_launch_order(const greb_params* p, int nx, int ny, int batch,
   for (size_t i = 0; i < tasks.size() && (int)i < capacity; ++i) {
     field[i] = tasks[i].field; k0[i] = tasks[i].rows & 0xff; k1[i] = (tasks[i].rows >> 8) & 0x1ff;
     up[i] = (tasks[i].rows & kRowsUp) != 0;
+  }
+  return (int)tasks.size();
+}
+
+int greb_substep_launch_order(const greb_params* p, int nx, int ny, int n_members, const float* kappa, int* field, int* k0,
+                              int* k1, int capacity) {
+  if (!p || nx < 12 || (nx & 3) || ny < 5 || ny > kMaxNy || n_members < 1 || capacity < 0 || (capacity > 0 && (!field || !k0 || !k1)))
+    return fail(nullptr, GREB_E_INVALID, "substep_launch_order: bad argument");
+  std::vector<RowTables> tabs((size_t)n_members);
+  std::vector<int> idx((size_t)n_members);
+  for (int m = 0; m < n_members; ++m) { compute_row_tables(*p, kappa ? kappa[m] : p->kappa, nx, ny, tabs[m]); idx[m] = m; }
+  if (!step_rows_supported(tabs.data(), n_members, nx, ny)) return 0;
+  std::vector<RowsTask> tasks;
+  step_rows_tasks(tabs.data(), idx.data(), n_members, ny, tasks);
+  for (size_t i = 0; i < tasks.size() && (int)i < capacity; ++i) {
+    field[i] = tasks[i].field; k0[i] = tasks[i].rows & 0xff; k1[i] = (tasks[i].rows >> 8) & 0x1ff;
   }
   return (int)tasks.size();
 }

@@ -54,7 +54,8 @@ EXPORTS = ["greb_params_default", "greb_engine_create", "greb_engine_flux_correc
            "greb_engine_last_error", "greb_engine_destroy", "greb_device_info", "greb_diffusion_batched",
            "greb_advection_batched", "greb_circulation_batched", "greb_diffusion_batched_dev",
            "greb_engine_point_physics", "greb_log_exp_switches", "greb_engine_set_experiment",
-           "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev", "greb_engine_set_state", "greb_release_caches", "greb_diffusion_launch_order"]
+           "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev", "greb_engine_set_state", "greb_release_caches", "greb_diffusion_launch_order",
+           "greb_substep_launch_order"]
 
 
 def _check(rc: int, h=None):
@@ -85,7 +86,8 @@ class Engine:
     qflux_correction (src/greb.f90:311-364), run() is the scenario loop (:228-234)."""
 
     def __init__(self, inp: workload.Inputs, params: abi.GrebParams | None = None, n_members: int = 1,
-                 overrides=None, device: int = 0, strict: bool = False, multilaunch: bool = False):
+                 overrides=None, device: int = 0, strict: bool = False, multilaunch: bool = False,
+                 row_strips: bool = False):
         L = lib()
         self.params = params or params_default()
         self.nx, self.ny, self.np, self.nm = inp.nx, inp.ny, inp.nx * inp.ny, n_members
@@ -98,7 +100,8 @@ class Engine:
                     setattr(ov[i], k, float(o.get(k, float("nan"))))
         self.h = C.c_void_p()
         rc = L.greb_engine_create(C.byref(self.params), inp.nx, inp.ny, C.byref(fields), n_members, ov, device,
-                                  (abi.F_STRICT if strict else 0) | (abi.F_MULTILAUNCH if multilaunch else 0), C.byref(self.h))
+                                  (abi.F_STRICT if strict else 0) | (abi.F_MULTILAUNCH if multilaunch else 0) |
+                                 (abi.F_ROW_STRIPS if row_strips else 0), C.byref(self.h))
         if rc != 0:
             msg = L.greb_engine_last_error(self.h).decode()
             if self.h:
@@ -216,6 +219,23 @@ def diffusion_launch_order(params, nx, ny, batch):
     if n:
         ptr = [a.ctypes.data_as(C.POINTER(C.c_int)) for a in out]
         assert f(C.byref(params), nx, ny, batch, *ptr, n) == n
+    return out
+
+
+def substep_launch_order(params, nx, ny, n_members, kappa=None):
+    """Host-only diagnostic: the task list of the engine's row-strip circulation sub-step, arrays (field, k0, k1) with
+    field = 2 * member + tracer (include/greb_engine.h: greb_substep_launch_order)."""
+    params = params if params is not None else params_default()
+    kap = None if kappa is None else np.ascontiguousarray(kappa, np.float32)
+    kp = None if kap is None else kap.ctypes.data_as(C.POINTER(C.c_float))
+    f = lib().greb_substep_launch_order
+    n = f(C.byref(params), nx, ny, n_members, kp, None, None, None, 0)
+    if n < 0:
+        _check(n)
+    out = [np.zeros(n, np.int32) for _ in range(3)]
+    if n:
+        ptr = [a.ctypes.data_as(C.POINTER(C.c_int)) for a in out]
+        assert f(C.byref(params), nx, ny, n_members, kp, *ptr, n) == n
     return out
 
 

@@ -82,6 +82,12 @@ typedef struct greb_member_overrides {
                                  where the fused one-CU-per-member kernel applies (96x48); grids that
                                  do not fit one CU, e.g. 384x192, always use it */
 
+#define GREB_F_ROW_STRIPS 4u /* 384-wide grids: take the row-strip form of the circulation sub-step
+                                (greb_step_rows.hip: one wavefront per strip of rows, no workgroup barrier) for every
+                                member count and in STRICT arithmetic too.  Default: FAST with at most 8 members,
+                                where it is the faster form (one member: 24.0 against 25.1 us per sub-step launch;
+                                from ~16 members on the band kernels win) */
+
 typedef struct greb_engine greb_engine;
 
 /* Create an engine for n_members ensemble members on HIP device `device`.
@@ -182,6 +188,10 @@ int greb_release_caches(void);
  * tests check that every row of every field is written exactly once. */
 int greb_diffusion_launch_order(const greb_params* p, int nx, int ny, int batch, int* field, int* k0, int* k1, int* up,
                                 int capacity);
+/* The same for the engine's row-strip circulation sub-step (GREB_F_ROW_STRIPS): field = 2 * member + tracer; kappa:
+ * [n_members] diffusivities (own sub-cycle tables) or NULL for p->kappa everywhere. */
+int greb_substep_launch_order(const greb_params* p, int nx, int ny, int n_members, const float* kappa, int* field, int* k0,
+                              int* k1, int capacity);
 
 /* Point physics of one step for a batch of columns sets (tests): SWradiation :367-403,
  * LWradiation :407-434, hydro :438-469, deep_ocean :495-525, seaice :472-492 evaluated by the

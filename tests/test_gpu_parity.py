@@ -325,7 +325,29 @@ def test_chain_clamp_g384(eng_mod, oracle_lib, inputs384):
     assert n_clamped > 0  # the cases do drive points to the clamp
 
 
-@pytest.mark.parametrize("mode", ["strict", "fast", "pairs"])
+def test_row_strip_substep_equals_band_kernel_strict(eng_mod, inputs384):
+    """The row-strip circulation sub-step (greb_step_rows.hip; GREB_F_ROW_STRIPS) in STRICT arithmetic against the band
+    kernel in STRICT arithmetic: the same expression trees through completely different data movement (wavefront-private
+    LDS rings fed by LDS-DMA, 6 longitudes per lane, wave rotates for the zonal halo) -- one flux-correction month and a
+    scenario month of three members with different physics (own kappa: own sub-cycle tables) must agree BIT FOR BIT."""
+    from greb_climate_model_amd import abi
+    g = load_golden("g384_physpar.npz")
+    ov = [dict(zip(("da_ice", "a_no_ice", "a_cloud", "kappa"), map(float, g["overrides"][m]))) for m in (0, 1, 4)]
+    out = []
+    for strips in (False, True):
+        e = eng_mod.Engine(inputs384, abi.default_params(ipx=380, ipy=152), n_members=3, overrides=ov, strict=True, row_strips=strips)
+        e.flux_correction(1)
+        mon, yr = e.run(1, 680.0)
+        st = [e.state(m) for m in range(3)]
+        e.close()
+        out.append((mon, yr, st))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        assert np.array_equal(a, b)
+    assert np.isfinite(out[1][0]).all()
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast", "pairs", "strips40"])
 def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
     """BASELINE config 3 in miniature against the REFERENCE compiled at 384x192 (g384_short.npz): 1+2 yr, 2xCO2.
     strict / fast: 2 members on the scalar any-grid kernel; pairs: 40 members (the engine takes the pair kernel from 28 on), the
@@ -333,8 +355,8 @@ def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
     from greb_climate_model_amd import abi
     g = load_golden("g384_short.npz")
     p = abi.default_params(ipx=380, ipy=152)
-    nm = 40 if mode == "pairs" else 2
-    e = eng_mod.Engine(inputs384, p, n_members=nm, strict=mode == "strict")
+    nm = 40 if mode in ("pairs", "strips40") else 2  # fast with 2 members takes the row-strip sub-step by default
+    e = eng_mod.Engine(inputs384, p, n_members=nm, strict=mode == "strict", row_strips=mode == "strips40")
     yf = e.flux_correction(1)
     co2 = np.full((nm, 2), 340.0, np.float32); co2[-1] = 680.0
     mon, yr = e.run(2, co2)

@@ -44,3 +44,22 @@ def test_last_tasks_are_the_short_streaming_strips():
 def test_other_grids_keep_the_band_kernel():
     for nx, ny in ((96, 48), (192, 96)):
         assert len(engine.diffusion_launch_order(abi.default_params(), nx, ny, 4)[0]) == 0
+
+
+@pytest.mark.parametrize("n_members", [1, 3, 8, 40])
+def test_substep_order_is_a_partition_and_dearest_first(n_members):
+    """The engine's row-strip sub-step (greb_step_rows.hip: step_rows_tasks): every row of every (member, tracer) field
+    exactly once -- with per-member diffusivities, i.e. different sub-cycle tables per member -- and the strips that hold
+    the long polar chains at the head of the launch."""
+    p = abi.default_params()
+    kappa = np.float32(8e5) * (1 + 0.05 * np.sin(np.arange(n_members)))  # stays above 7.27e5: no 1 800-sweep polar rows
+    field, k0, k1 = engine.substep_launch_order(p, 384, 192, n_members, kappa.astype(np.float32))
+    assert field.min() == 0 and field.max() == 2 * n_members - 1
+    cover = np.zeros((2 * n_members, 192), np.int32)
+    for f, a, b in zip(field, k0, k1):
+        assert 0 <= a < b <= 192
+        cover[f, a:b] += 1
+    assert (cover == 1).all()
+    head = [(a, b) for a, b in zip(k0[: 4 * n_members], k1[: 4 * n_members])]
+    assert all(a <= 1 < b or a <= 190 < b for a, b in head)  # rows 1 and 190: the 232-sweep rows of the default grid
+    assert len(engine.substep_launch_order(p, 96, 48, 2)[0]) == 0  # other grids keep the band kernels
