@@ -29,8 +29,7 @@
 #include <mutex>
 #include <vector>
 
-#include "greb_kernels.h"
-#include "greb_stencil.h"
+#include "greb_rows.h"
 
 namespace greb {
 namespace {
@@ -38,7 +37,10 @@ namespace {
 constexpr int kRNx = 384, kRP = 6;
 constexpr unsigned kRowB = kRNx * 4;              // 1 536 bytes of a row
 constexpr unsigned kSlotB = 2 * kRowB;            // a (T, wz) row pair in LDS: T row | wz tail (512 B) | wz head (1 024 B)
-constexpr int kRowsSlots = 3;                     // rows in flight or waiting per wavefront
+#ifndef GREB_ROWS_SLOTS
+#define GREB_ROWS_SLOTS 3
+#endif
+constexpr int kRowsSlots = GREB_ROWS_SLOTS;       // rows in flight or waiting per wavefront
 constexpr unsigned kRowsLdsB = kRowB + kRowsSlots * kSlotB; // the output row, then the slots
 
 // Everything the kernel needs to know about the rows travels BY VALUE (kernarg, scalar loads): no device-side table
@@ -70,8 +72,8 @@ struct Walk {
   unsigned aT, aW[3], aO, aR0, aR1; // LDS byte addresses of this lane (inside a slot / the output row)
   int row0, dir, m;  // the walk reads rows row0, row0 + dir, ..., row0 + m*dir
   int ops;           // vector-memory operations issued so far
-  unsigned long long gend; // 16 bits per slot: `ops` right after the LDS-DMA of the row now in slot s was issued (one
-                           // word, not an array: a dynamically indexed array is kept in scratch)
+  unsigned long long gend, gend2; // 16 bits per slot: `ops` right after the LDS-DMA of the row now in slot s was issued
+                                  // (two words, not an array: a dynamically indexed array is kept in scratch)
   int slot;          // the slot the next row of the walk arrives in (rows go round the slots)
 };
 
@@ -83,19 +85,16 @@ __device__ __forceinline__ void issue_row(Walk& c, int x, int slot) {
   glds16<AUX>(c.p2 + ro, dst + 256);
   glds16<AUX>(c.wf + ro + 4 * c.lane, dst + 512);
   c.ops += 3;
-  c.gend = (c.gend & ~(0xffffull << (16 * slot))) | ((unsigned long long)c.ops << (16 * slot));
+  const int sh = 16 * (slot & 3);
+  const unsigned long long old = (slot >> 2) ? c.gend2 : c.gend;
+  const unsigned long long v = (old & ~(0xffffull << sh)) | ((unsigned long long)c.ops << sh);
+  if (slot >> 2) c.gend2 = v; else c.gend = v;
 }
 
 // the row in `slot` has landed: all but the `younger` operations issued after its LDS-DMA may still be in flight
-#define GREB_VMCNT_CASE(n) case n: GREB_VMCNT(n); break;
 __device__ __forceinline__ void wait_row(const Walk& c, int slot) {
-  const int younger = c.ops - (int)((c.gend >> (16 * slot)) & 0xffff);
-  switch (younger < 15 ? younger : 15) {
-    GREB_VMCNT_CASE(0) GREB_VMCNT_CASE(1) GREB_VMCNT_CASE(2) GREB_VMCNT_CASE(3) GREB_VMCNT_CASE(4) GREB_VMCNT_CASE(5)
-    GREB_VMCNT_CASE(6) GREB_VMCNT_CASE(7) GREB_VMCNT_CASE(8) GREB_VMCNT_CASE(9) GREB_VMCNT_CASE(10) GREB_VMCNT_CASE(11)
-    GREB_VMCNT_CASE(12) GREB_VMCNT_CASE(13) GREB_VMCNT_CASE(14)
-    default: GREB_VMCNT(15); break;
-  }
+  const int younger = c.ops - (int)((((slot >> 2) ? c.gend2 : c.gend) >> (16 * (slot & 3))) & 0xffff);
+  rows::wait_all_but(younger);
 }
 
 __device__ __forceinline__ void read_row(const Walk& c, int slot, float (&T)[6], float (&w)[6]) {
@@ -213,7 +212,9 @@ __device__ __forceinline__ void row_step(Walk& c, const RowsArgs& a, RowState<ST
       Tw[j] = wave_from_prev(cur.T[3 + j]); Tw[9 + j] = wave_from_next(cur.T[j]);
       ww[j] = wave_from_prev(cur.w[3 + j]); ww[9 + j] = wave_from_next(cur.w[j]);
     }
+    if (dbg & 8) __builtin_amdgcn_s_setprio(0); // experiment: the streaming waves issue ahead of the chains
     chain_window<STRICT, 6>(Tw, ww, u0, cc, t2, false, (int)c.lane, (dbg & 4) != 0);
+    if (dbg & 8) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int j = 0; j < 6; ++j) T1h[j] = Tw[3 + j];
   } else {
@@ -277,8 +278,9 @@ __global__ __launch_bounds__(64) void dif_rows_kernel(const float* __restrict__ 
   c.aO = lb + 24 * c.lane;
   c.aR0 = lb + 16 * c.lane;
   c.aR1 = lb + (c.lane < 32 ? 1024 + 16 * c.lane : 0);
-  c.ops = 0; c.gend = 0;
-  static_assert(kRowsSlots <= 4, "gend holds four 16-bit counters");
+  c.ops = 0; c.gend = 0; c.gend2 = 0;
+  if (dbg & 8) __builtin_amdgcn_s_setprio(2);
+  static_assert(kRowsSlots <= 8, "gend, gend2 hold eight 16-bit counters");
   // the walk: rows lo .. hi (the strip and its halo rows inside the grid), upwards or downwards
   const int lo = k0 > 0 ? k0 - 1 : 0, hi = k1 < ny ? k1 : ny - 1;
   c.dir = (task.rows & kRowsUp) ? 1 : -1;

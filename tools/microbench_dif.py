@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from greb_climate_model_amd import engine
 engine.use_tuning_build()  # GREB_DEBUG_* knobs exist only in the -DGREB_TUNING library
+if os.environ.get("GREB_LIB"):
+    engine._lib_path = os.path.abspath(os.environ["GREB_LIB"])  # a variant library (A/B of compile-time choices)
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 nx, ny = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (96, 48)
