@@ -438,7 +438,8 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
 
     r, dt, ok = year_rate(1, None)
     out["config3_single_member"] = {"years_per_s": round(r, 3), "us_per_substep_launch": round(dt / (730 * 25) * 1e6, 2),
-                                    "finite": ok, "bound": "latency of one wave's 225-sweep polar chain per launch"}
+                                    "finite": ok, "bound": "latency of one wavefront's 232-sweep polar row per launch: 22.0 of the ~23.5 us "
+                                                           "(profiles/r03_g384_substep_stamps.txt: 210 cycles per dependent sweep)"}
     ov = ensemble.perturbed_physics(64, p)
     as_dicts = lambda rows: [dict(zip(ensemble.PERTURBED, map(float, row))) for row in rows]
     slow = ov[:, 3] < 7.27e5
@@ -465,7 +466,8 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
     keep = ov[~slow]
     r, dt, ok = year_rate(len(keep), as_dicts(keep))
     out["config5_without_those_members"] = {"members": int(len(keep)), "member_years_per_s": round(r, 2), "finite": ok,
-                                            "bound": "workgroup throughput of the pair kernel: LDS staging not overlapped with arithmetic at 8 waves per CU"}
+                                            "bound": "row-strip sub-step (greb_step_rows.hip): two wavefronts per SIMD at 187 VGPRs, ~3 900 cycles per streamed row and wavefront "
+                                                     "(tools/stamp_step_rows.py); the launch cannot be shorter than its 232-sweep polar rows (22 us)"}
     # standalone diffusion sweep, HIP events on the launching stream
     batch = 1024
     n = batch * nx * ny

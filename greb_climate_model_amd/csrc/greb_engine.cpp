@@ -108,8 +108,6 @@ struct greb_engine {
   bool shared_corr = true; // all members share physics -> one flux-correction set
   bool fused = true;       // every member has the 96x48 default sub-cycling layout -> fused member kernel
   float *Xa = nullptr, *Xb = nullptr, *red = nullptr, *W2 = nullptr; // any-grid (multi-launch) engine work arrays
-  float* W2p = nullptr; // [np][{wz_air,wz_vapor}] for the pair form of the sub-step (FAST, 384-wide grids)
-  bool pairs = false;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;               // device -> host delivery of the monthly means
   hipEvent_t ev_done[2] = {nullptr, nullptr};      // year written into staging slot i
@@ -190,17 +188,12 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     return 0;
   }
   const size_t np = (size_t)e->np;
-  // FAST on a 384-wide grid: both tracers of a member as pairs (greb_pair_sweep.hip); the experiment that diffuses
-  // but does not advect vapour needs per-tracer winds and takes the scalar kernel.
-  // Few members: the launch is as long as the 225-sweep polar chain and the scalar kernel, whose workgroups are
-  // smaller, is a little ahead (us per launch, scalar / pairs: 8 members 28.8 / 30.8, 24: 30.3 / 32.4); from ~28
-  // members on the pair kernel's packed single-sweep rows win (32: 38.0 / 33.4, 40: 45.5 / 35.4, 62: 68.0 / 52.6).
-  static const int pair_min = tuning_int("GREB_PAIR_MIN", 28); // -DGREB_TUNING builds only
-  // the row-strip sub-step (greb_step_rows.hip) is the faster form for a few FAST members, whose launch is as long as
-  // one polar chain (us per launch, strips / bands: 1 member 24.0 / 25.1, 4: 28.1 / 28.4, 16: 29.6 / 29.4, 24: 33.7 / 30.5,
-  // 62: 65.8 / 48.0; STRICT 1 member 73.6 / 64.7)
-  static const int rows_max = tuning_int("GREB_STEP_ROWS_MAX", 8); // -DGREB_TUNING builds only
-  const bool rows = e->step_rows && (e->step_rows_always || (!e->strict && nrun <= rows_max));
+  // 384-wide grids, FAST: the row-strip sub-step (greb_step_rows.hip) at every member count -- us per launch against
+  // the band kernels it replaces (the scalar sweep_kernel<fused> below 28 members, a (Tair,q)-pair band kernel above, round
+  // 2): 1 member 23.2 / 25.1, 8: 27.8 / 28.8, 24: 30.0 / 30.5, 40: 35.6 / 35.2, 48: 39.6 / 40.5, 62: 40.8 / 48.0.
+  // STRICT keeps the band kernel (1 member 64.7 against 74.6 us: its two chains per row run one after the other in
+  // one wave here); GREB_F_ROW_STRIPS takes the strips there too.
+  const bool rows = e->step_rows && (e->step_rows_always || !e->strict);
   const RowsTask* step_tasks = nullptr;
   int n_step_tasks = 0;
   if (rows) {
@@ -212,9 +205,7 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     }
     step_tasks = it->second.first; n_step_tasks = it->second.second;
   }
-  const bool pairs = !rows && e->pairs && nrun >= pair_min && !(e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY);
-  if (pairs) HIP_TRY(e, launch_pack_pairs(e->state, e->Xa, e->np, nrun, e->stream));
-  else HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
+  HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
   for (int s = 0; s < kNT; ++s) {
     const long long it = a.it0 + s;
     const int ityr = (int)((it - 1) % kNT) + 1;
@@ -224,8 +215,6 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
       if (rows)
         HIP_TRY(e, launch_substep_rows(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, step_tasks,
                                        n_step_tasks, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
-      else if (pairs)
-        HIP_TRY(e, launch_substep_pairs(cur, e->W2p, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->ny, nrun, e->stream));
       else
         HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
                                         e->ny, nrun, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
@@ -233,7 +222,7 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     }
     MemberArgs b = a;
     b.it0 = it; b.nsteps = 1; // the step kernel derives its clock from it0; year indices are those of `a`
-    HIP_TRY(e, launch_physics_step(b, cur, e->Xa, e->red, nrun, e->strict, e->stream, pairs));
+    HIP_TRY(e, launch_physics_step(b, cur, e->Xa, e->red, nrun, e->strict, e->stream));
     if (ityr == kNT && a.yearly)
       HIP_TRY(e, launch_yearly(e->red, a.yearly, e->np, e->nx, a.ipx, a.ipy, a.yearly_years, a.yearly_year0, nrun, e->strict, e->stream));
   }
@@ -404,13 +393,6 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
     static const bool no_step_rows = tuning_int("GREB_NO_STEP_ROWS", 0) != 0; // -DGREB_TUNING builds only (A/B)
     e->step_rows = !no_step_rows && step_rows_supported(e->h_tabs.data(), (int)e->h_tabs.size(), nx, ny);
     e->step_rows_always = (flags & GREB_F_ROW_STRIPS) != 0;
-    e->pairs = !e->strict && pair_sweep_supported(nx, ny);
-    if (e->pairs) {
-      std::vector<float> w2p(2 * np);
-      for (size_t i = 0; i < np; ++i) { w2p[2 * i] = wz_air[i]; w2p[2 * i + 1] = wz_vapor[i]; }
-      HIP_TRY(e, dev_alloc(&e->W2p, 2 * np));
-      HIP_TRY(e, hipMemcpy(e->W2p, w2p.data(), 2 * np * sizeof(float), hipMemcpyHostToDevice));
-    }
   }
   return 0;
 }
@@ -421,7 +403,7 @@ int greb_engine_destroy(greb_engine* e) {
   void* ptrs[] = {e->z_topo, e->glacier, e->sw_solar, e->tclim, e->qclim, e->uclim, e->vclim, e->mldclim,
                   e->cldclim, e->swetclim, e->toclim, e->z_ocean, e->wz_air, e->wz_vapor, e->state, e->acc,
                   e->corr, e->corr_index, e->tab_index, e->tabs, e->phys, e->co2_dev, e->monthly_dev, e->yearly_dev,
-                  e->Xa, e->Xb, e->red, e->W2, e->W2p};
+                  e->Xa, e->Xb, e->red, e->W2};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   for (auto& kv : e->step_tasks) if (kv.second.first) (void)hipFree(kv.second.first);
   for (int i = 0; i < 2; ++i) {

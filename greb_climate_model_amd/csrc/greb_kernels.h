@@ -117,12 +117,7 @@ hipError_t launch_substep_fused(const float* X, const float* W2, const float* u,
                                 const RowTables* tabs, const int* tab_index, int nx, int ny, int n_members,
                                 bool strict, hipStream_t s, bool calm_vapor = false);
 hipError_t launch_physics_step(const MemberArgs& a, const float* X, float* Xout, float* red, int n_members,
-                               bool strict, hipStream_t s, bool pairs = false);
-// FAST pair form of the sub-step for 384-wide grids (greb_pair_sweep.hip): X2 [member][np][{Tair,q}], W2p [np][2]
-bool pair_sweep_supported(int nx, int ny);
-hipError_t launch_substep_pairs(const float* X2, const float* W2p, const float* u, const float* v, float* Xnew2,
-                                const RowTables* tabs, const int* tab_index, int ny, int n_members, hipStream_t s);
-hipError_t launch_pack_pairs(const float* state, float* X2, int np, int n_members, hipStream_t s);
+                               bool strict, hipStream_t s);
 hipError_t launch_yearly(const float* red, float* yearly, int np, int nx, int ipx, int ipy, int yearly_years,
                          int year_index, int n_members, bool strict, hipStream_t s);
 hipError_t launch_pack_tracers(const float* state, float* X, int np, int n_members, hipStream_t s);

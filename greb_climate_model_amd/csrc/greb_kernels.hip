@@ -397,8 +397,7 @@ hipError_t launch_substep_fused(const float* X, const float* W2, const float* u,
   return launch_sweep<kChainFused>(X, W2, u, v, Xnew, tabs, nx, ny, 2 * n_members, strict, s, 2, 1, tab_index, 2, calm_vapor ? 1 : 0);
 }
 
-// PAIRS: X / Xout are [member][np][{Tair,q}] (the pair engine's layout) instead of [member][2][np]
-template <bool STRICT, bool FLUX, bool EXP, bool PAIRS>
+template <bool STRICT, bool FLUX, bool EXP>
 // X and Xout may be the SAME buffer (run_year passes the current tracer buffer as both when the sub-step count is
 // even): every thread reads its own quad before it writes it and touches no other, so in-place is safe -- and the
 // pointers are therefore not __restrict__.
@@ -413,39 +412,22 @@ __global__ __launch_bounds__(256) void physics_step_kernel(MemberArgs a, const f
   float* state = a.state + (size_t)m * 5 * np;
   float* acc = a.acc + (size_t)m * 6 * np;
   float* corr = a.corr + (size_t)a.corr_index[m] * 3 * kNT * np;
-  f4 xTa, xq;
-  if (PAIRS) {
-    const f4 p0 = ld4(X + ((size_t)m * np + 4 * qd) * 2), p1 = ld4(X + ((size_t)m * np + 4 * qd) * 2 + 4);
-    xTa = f4{{p0.v[0], p0.v[2], p1.v[0], p1.v[2]}}; xq = f4{{p0.v[1], p0.v[3], p1.v[1], p1.v[3]}};
-  } else {
-    xTa = ld4(X + ((size_t)m * 2) * np + 4 * qd); xq = ld4(X + ((size_t)m * 2 + 1) * np + 4 * qd);
-  }
+  const f4 xTa = ld4(X + ((size_t)m * 2) * np + 4 * qd), xq = ld4(X + ((size_t)m * 2 + 1) * np + 4 * qd);
   f4 oTa, oq, tsm;
   physics_quad<STRICT, FLUX, EXP>(a, P, m, qd, ck, co2, state, acc, corr, xTa, xq, oTa, oq, tsm);
-  if (PAIRS) {
-    st4(Xout + ((size_t)m * np + 4 * qd) * 2, f4{{oTa.v[0], oq.v[0], oTa.v[1], oq.v[1]}});
-    st4(Xout + ((size_t)m * np + 4 * qd) * 2 + 4, f4{{oTa.v[2], oq.v[2], oTa.v[3], oq.v[3]}});
-  } else {
-    st4(Xout + ((size_t)m * 2) * np + 4 * qd, oTa);
-    st4(Xout + ((size_t)m * 2 + 1) * np + 4 * qd, oq);
-  }
+  st4(Xout + ((size_t)m * 2) * np + 4 * qd, oTa);
+  st4(Xout + ((size_t)m * 2 + 1) * np + 4 * qd, oq);
   if (ck.ityr == kNT) st4(red + (size_t)m * np + 4 * qd, tsm);
 }
 
 hipError_t launch_physics_step(const MemberArgs& a, const float* X, float* Xout, float* red, int n_members,
-                               bool strict, hipStream_t s, bool pairs) {
+                               bool strict, hipStream_t s) {
   void (*kern)(MemberArgs, const float*, float*, float*);
-  if (pairs) { // FAST only
-    if (a.xsw) kern = a.flux_phase ? physics_step_kernel<false, true, true, true> : physics_step_kernel<false, false, true, true>;
-    else kern = a.flux_phase ? physics_step_kernel<false, true, false, true> : physics_step_kernel<false, false, false, true>;
-    hipLaunchKernelGGL(kern, dim3((a.np / 4 + 255) / 256, n_members), dim3(256), 0, s, a, X, Xout, red);
-    return hipGetLastError();
-  }
   if (a.xsw) {
-    if (a.flux_phase) kern = strict ? physics_step_kernel<true, true, true, false> : physics_step_kernel<false, true, true, false>;
-    else kern = strict ? physics_step_kernel<true, false, true, false> : physics_step_kernel<false, false, true, false>;
-  } else if (a.flux_phase) kern = strict ? physics_step_kernel<true, true, false, false> : physics_step_kernel<false, true, false, false>;
-  else kern = strict ? physics_step_kernel<true, false, false, false> : physics_step_kernel<false, false, false, false>;
+    if (a.flux_phase) kern = strict ? physics_step_kernel<true, true, true> : physics_step_kernel<false, true, true>;
+    else kern = strict ? physics_step_kernel<true, false, true> : physics_step_kernel<false, false, true>;
+  } else if (a.flux_phase) kern = strict ? physics_step_kernel<true, true, false> : physics_step_kernel<false, true, false>;
+  else kern = strict ? physics_step_kernel<true, false, false> : physics_step_kernel<false, false, false>;
   hipLaunchKernelGGL(kern, dim3((a.np / 4 + 255) / 256, n_members), dim3(256), 0, s, a, X, Xout, red);
   return hipGetLastError();
 }

@@ -96,6 +96,28 @@ __device__ __forceinline__ void read_pair(const LaneAddr& L, unsigned base, floa
   B[0] = w0.x; B[1] = w0.y; B[2] = w1.x; B[3] = w1.y; B[4] = w2.x; B[5] = w2.y;
 }
 
+// the same in two halves, so that independent work can run under the LDS latency: the six ds_read_b64 are issued into
+// `raw`, whose registers must not be touched until read_pair_finish has waited for them
+struct PairRaw { v2 t0, t1, t2, w0, w1, w2; };
+__device__ __forceinline__ void read_pair_issue(const LaneAddr& L, unsigned base, PairRaw& raw) {
+  const unsigned at = L.a + base, aw0 = L.b[0] + base, aw1 = L.b[1] + base, aw2 = L.b[2] + base;
+  asm volatile("ds_read_b64 %[t0], %[at]\n\t"
+               "ds_read_b64 %[t1], %[at] offset:8\n\t"
+               "ds_read_b64 %[t2], %[at] offset:16\n\t"
+               "ds_read_b64 %[w0], %[aw0]\n\t"
+               "ds_read_b64 %[w1], %[aw1]\n\t"
+               "ds_read_b64 %[w2], %[aw2]"
+               : [t0] "=&v"(raw.t0), [t1] "=&v"(raw.t1), [t2] "=&v"(raw.t2), [w0] "=&v"(raw.w0), [w1] "=&v"(raw.w1), [w2] "=&v"(raw.w2)
+               : [at] "v"(at), [aw0] "v"(aw0), [aw1] "v"(aw1), [aw2] "v"(aw2)
+               : "memory");
+}
+__device__ __forceinline__ void read_pair_finish(PairRaw& raw, float (&A)[6], float (&B)[6]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(raw.t0), "+v"(raw.t1), "+v"(raw.t2), "+v"(raw.w0), "+v"(raw.w1), "+v"(raw.w2)::"memory");
+  A[0] = raw.t0.x; A[1] = raw.t0.y; A[2] = raw.t1.x; A[3] = raw.t1.y; A[4] = raw.t2.x; A[5] = raw.t2.y;
+  B[0] = raw.w0.x; B[1] = raw.w0.y; B[2] = raw.w1.x; B[3] = raw.w1.y; B[4] = raw.w2.x; B[5] = raw.w2.y;
+}
+
 // six results per lane -> the output row at byte address `base` -> sixteen bytes per lane (q1: lanes 0-31 only)
 __device__ __forceinline__ void transpose_out(const LaneAddr& L, unsigned base, const float (&o)[6], vfloat4& q0, vfloat4& q1) {
   const v2 p0{o[0], o[1]}, p1{o[2], o[3]}, p2{o[4], o[5]};

@@ -347,16 +347,17 @@ def test_row_strip_substep_equals_band_kernel_strict(eng_mod, inputs384):
     assert np.isfinite(out[1][0]).all()
 
 
-@pytest.mark.parametrize("mode", ["strict", "fast", "pairs", "strips40"])
+@pytest.mark.parametrize("mode", ["strict", "fast", "fast40", "strict_strips"])
 def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
     """BASELINE config 3 in miniature against the REFERENCE compiled at 384x192 (g384_short.npz): 1+2 yr, 2xCO2.
-    strict / fast: 2 members on the scalar any-grid kernel; pairs: 40 members (the engine takes the pair kernel from 28 on), the
-    (Tair,q)-pair kernel of greb_pair_sweep.hip.  Months 1, 12, 24 in full, every month by zonal means and polar rows."""
+    strict: 2 members on the band kernel (greb_kernels.hip: sweep_kernel<fused>); fast / fast40: 2 / 40 members on the
+    row-strip sub-step (greb_step_rows.hip); strict_strips: the row strips in STRICT arithmetic (GREB_F_ROW_STRIPS).
+    Months 1, 12, 24 in full, every month by zonal means and polar rows."""
     from greb_climate_model_amd import abi
     g = load_golden("g384_short.npz")
     p = abi.default_params(ipx=380, ipy=152)
-    nm = 40 if mode in ("pairs", "strips40") else 2  # fast with 2 members takes the row-strip sub-step by default
-    e = eng_mod.Engine(inputs384, p, n_members=nm, strict=mode == "strict", row_strips=mode == "strips40")
+    nm = 40 if mode == "fast40" else 2
+    e = eng_mod.Engine(inputs384, p, n_members=nm, strict=mode.startswith("strict"), row_strips=mode == "strict_strips")
     yf = e.flux_correction(1)
     co2 = np.full((nm, 2), 340.0, np.float32); co2[-1] = 680.0
     mon, yr = e.run(2, co2)
@@ -364,25 +365,25 @@ def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
     last = mon[-1].reshape(24, 5, 192, 384)
     _check_run(last[[0, 11, 23]], g["monthly_sel"], f"g384 {mode}")
     _g384_reductions_close(last, g, f"g384 {mode}")
-    yearly_close(np.concatenate([yf[-1], yr[-1]]), g["yearly"], mode == "strict", 384 * 192)
-    if mode != "strict":
+    yearly_close(np.concatenate([yf[-1], yr[-1]]), g["yearly"], mode.startswith("strict"), 384 * 192)
+    if not mode.startswith("strict"):
         fast_global_mean_is_the_better_one(yr[-1][1][0], g["yearly"][2][0], mon[-1, 1], f"384x192 {mode} year 2")
     assert rms(mon[0, 1, 11, 0], mon[-1, 1, 11, 0]) > 1e-2  # the members differ (CO2)
     if nm > 2:
         assert np.array_equal(mon[0], mon[1])  # replicas agree bit for bit
 
 
-@pytest.mark.parametrize("mode", ["strict", "fast", "pairs", "pairs60"])
+@pytest.mark.parametrize("mode", ["strict", "fast", "fast40", "fast60"])
 def test_config5_perturbed_members_g384_vs_reference(eng_mod, inputs384, mode):
     """BASELINE config 5 in miniature: perturbed-physics members at 384x192 -- per-member RowTables (own kappa),
-    own flux corrections (shared_corr = false), the multi-launch engine and, in `pairs`, the pair kernel -- against
+    own flux corrections (shared_corr = false), the multi-launch engine with the row-strip sub-step (fast*) -- against
     five separate runs of the reference with the same &PHYSICS_PAR (g384_physpar.npz), 1+1 yr.  Member 4 has
     kappa = 7.2e5: 1 800 dependent sweeps in each polar row (inherited semantics, src/greb.f90:652-654)."""
     from greb_climate_model_amd import abi
     g = load_golden("g384_physpar.npz")
     ov = g["overrides"]
-    # 40 members: the pair kernel with 4-row bands; 60 members: with 8-row bands (greb_pair_sweep.hip: pair_band_rows)
-    reps = {"pairs": 8, "pairs60": 12}.get(mode, 1)
+    # 40 / 60 members: the launch order of the row strips is cut coarser as the member count grows (step_rows_tasks)
+    reps = {"fast40": 8, "fast60": 12}.get(mode, 1)
     overrides = [dict(zip(("da_ice", "a_no_ice", "a_cloud", "kappa"), map(float, ov[m % 5]))) for m in range(5 * reps)]
     e = eng_mod.Engine(inputs384, abi.default_params(ipx=380, ipy=152), n_members=5 * reps, overrides=overrides,
                        strict=mode == "strict")

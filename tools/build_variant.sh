@@ -7,7 +7,7 @@ tag=$1; shift
 mkdir -p variants
 C=greb_climate_model_amd/csrc
 objs=""
-for s in greb_engine.cpp greb_kernels.hip greb_member.hip greb_ensemble.hip greb_pair_sweep.hip greb_rows.hip greb_step_rows.hip; do
+for s in greb_engine.cpp greb_kernels.hip greb_member.hip greb_ensemble.hip greb_rows.hip greb_step_rows.hip; do
   o=$C/_obj/${s%.*}_tuning.o
   case $s in greb_rows.hip|greb_step_rows.hip)
     o=variants/${s%.*}_$tag.o

@@ -69,8 +69,30 @@ def derive(sq, lds, stats):
             print(f"    LDS active                 {100 * c['SQ_LDS_IDX_ACTIVE'] / busy:.1f} % of the busy cycles")
 
 
+def traffic_json(fetch, write):
+    """profiles/rNN_roofline_traffic.json: HBM-side bytes per launch of the 96x48 roofline kernel (bench.py reads it)."""
+    import json
+    key = "diffusion_stream_kernel<false"
+    vals = {}
+    for f, name in ((fetch, "FETCH_SIZE"), (write, "WRITE_SIZE")):
+        agg, ndisp = load(f)
+        for k, d in agg.items():
+            if key in k:
+                vals[name] = d[name] / len(ndisp[k])
+    fk, wk = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+    print(json.dumps({"kernel": "greb::diffusion_stream_kernel<false, 96, 48>",
+                      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python tools/microbench_dif.py 16384`, "
+                                "MI355X (tools/verify_round.sh profiles).  Units: KiB per launch; FETCH_SIZE x2 on gfx950 "
+                                "(MI355X_MICROARCH.md, HBM section)",
+                      "batch": 16384, "fetch_size_kb_per_launch": round(fk), "write_size_kb_per_launch": round(wk),
+                      "gfx950_fetch_correction": 2.0, "traffic_bytes_per_launch": round((2 * fk + wk) * 1024),
+                      "algorithmic_bytes_per_launch": 12 * 16384 * 96 * 48}, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1:2] == ["--derive"]:
         derive(*sys.argv[2:5])
+    elif sys.argv[1:2] == ["--traffic-json"]:
+        traffic_json(*sys.argv[2:4])
     else:
         raw(sys.argv[1:])
