@@ -171,6 +171,8 @@ def main():
             dist.init_process_group(backend)
 
     from greb_climate_model_amd import engine, ensemble, workload
+    if os.environ.get("GREB_BENCH_LIB"):  # A/B of a variant library (tools/build_member_variant.sh); never set by the driver
+        engine._lib_path = os.path.abspath(os.environ["GREB_BENCH_LIB"])
     K, W, M = args.steps, args.warmup, args.members
     inp = workload.make_inputs()
     params = engine.params_default()

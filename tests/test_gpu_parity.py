@@ -130,6 +130,32 @@ def test_diffusion_g384_strict(eng_mod, params, oracle_lib):
     o.close()
 
 
+def test_row_strip_diffusion_ragged_batches_and_other_tables(eng_mod, oracle_lib, inputs384):
+    """The 384-wide row-strip diffusion kernel (greb_rows.hip) away from the benchmark shape: batches that do not fill
+    the launch order's groups of eight fields (1, 3, 11 fields), and another diffusivity (kappa = 6.5e5: other sub-cycle
+    tables -- 1 800 sweeps in the polar rows, 277 in the next -- hence other strips).  STRICT bit-exact against the oracle,
+    FAST within the re-association tolerance, every field independent of its batch neighbours."""
+    from greb_climate_model_amd import abi
+    nx, ny, inp = 384, 192, inputs384
+    for kappa, batches in ((None, (1, 3, 11)), (6.5e5, (5,))):
+        p = abi.default_params()
+        if kappa is not None:
+            p.kappa = kappa
+        o = oracle_lib.Oracle(inp, p)
+        wa, wv = o.field(5).copy(), o.field(6).copy()
+        for nb in batches:
+            X = np.stack([(inp.tclim[7 * i % 730] + np.float32(0.25 * i)).astype(np.float32) if i % 2 == 0 else inp.qclim[31 * i % 730] for i in range(nb)])
+            W = np.stack([wa if i % 2 == 0 else wv for i in range(nb)])
+            ds = eng_mod.diffusion(X, W, p, strict=True)
+            df = eng_mod.diffusion(X, W, p)
+            for i in range(nb):
+                ref = o.diffusion(X[i], W[i])
+                assert np.array_equal(ds[i], ref), (nx, ny, nb, i)
+                err = np.abs(df[i].astype(np.float64) - ref)
+                assert err.max() <= 4e-6 * max(np.abs(ref).max(), 1e-30) + 2 * np.spacing(np.abs(X[i]).max()), (nx, ny, nb, i, err.max())
+        o.close()
+
+
 # ------------------------------------------------------------------------------------ point physics
 @pytest.mark.parametrize("ityr", [1, 365, 730])
 def test_point_physics_vs_golden(eng_mod, params, routine_golden, inputs, ityr):
