@@ -29,6 +29,11 @@ __device__ __forceinline__ void glds16(const float* g, lfloat* l) {
   __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 16, 0, AUX);
 }
 
+// The hand-counted vmcnt scheme needs the vector-memory operations in PROGRAM order: a later LDS-DMA or store scheduled
+// ahead of an earlier one would be counted as younger than it is, and a counted wait could then return before the row
+// it waits for has landed.  Nothing emitted, the compiler just may not move memory operations across it.
+__device__ __forceinline__ void order_fence() { asm volatile("" ::: "memory"); }
+
 #define GREB_ROWS_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define GREB_ROWS_VMCASE(n) case n: GREB_ROWS_VMCNT(n); break;
 // every vector-memory operation of this wavefront has completed except (at most) the `younger` most recent ones
@@ -76,6 +81,7 @@ __device__ __forceinline__ void issue_pair(const float* a_row, const float* b_ro
   glds16<AUX>(a_row + 4 * lane, dst);
   glds16<AUX>(halves_row, dst + 256);
   glds16<AUX>(b_row + 4 * lane, dst + 512);
+  order_fence();
 }
 
 // both rows of the pair in the slot at byte address `base`, 6 floats per lane each

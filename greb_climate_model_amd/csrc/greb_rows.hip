@@ -34,9 +34,8 @@
 namespace greb {
 namespace {
 
-constexpr int kRNx = 384, kRP = 6;
-constexpr unsigned kRowB = kRNx * 4;              // 1 536 bytes of a row
-constexpr unsigned kSlotB = 2 * kRowB;            // a (T, wz) row pair in LDS: T row | wz tail (512 B) | wz head (1 024 B)
+using namespace rows;
+constexpr int kRNx = kNx;
 #ifndef GREB_ROWS_SLOTS
 #define GREB_ROWS_SLOTS 3
 #endif
@@ -52,16 +51,6 @@ struct RowsArgs {
                                    // wait for one drains the LDS-DMA queue)
 };
 
-typedef __attribute__((address_space(1))) const void gvoid;
-typedef __attribute__((address_space(3))) void lvoid;
-
-template <int AUX>
-__device__ __forceinline__ void glds16(const float* g, lfloat* l) {
-  __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 16, 0, AUX);
-}
-
-#define GREB_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
 struct Walk {
   const float* Tf;   // this field's T1
   const float* wf;   // ... wz
@@ -69,7 +58,8 @@ struct Walk {
   float* of;         // ... dX
   lfloat* lds;
   unsigned lane;
-  unsigned aT, aW[3], aO, aR0, aR1; // LDS byte addresses of this lane (inside a slot / the output row)
+  LaneAddr L;        // LDS byte addresses of this lane (inside a slot / the output row)
+  unsigned lb;       // byte address of the wavefront's LDS
   int row0, dir, m;  // the walk reads rows row0, row0 + dir, ..., row0 + m*dir
   int ops;           // vector-memory operations issued so far
   unsigned long long gend, gend2; // 16 bits per slot: `ops` right after the LDS-DMA of the row now in slot s was issued
@@ -80,10 +70,7 @@ struct Walk {
 template <int AUX>
 __device__ __forceinline__ void issue_row(Walk& c, int x, int slot) {
   const int ro = x * kRNx;
-  lfloat* dst = c.lds + (kRowB + slot * kSlotB) / 4;
-  glds16<AUX>(c.Tf + ro + 4 * c.lane, dst);
-  glds16<AUX>(c.p2 + ro, dst + 256);
-  glds16<AUX>(c.wf + ro + 4 * c.lane, dst + 512);
+  issue_pair<AUX>(c.Tf + ro, c.wf + ro, c.p2 + ro, c.lds + (kRowB + slot * kSlotB) / 4, c.lane); // ends in an order_fence
   c.ops += 3;
   const int sh = 16 * (slot & 3);
   const unsigned long long old = (slot >> 2) ? c.gend2 : c.gend;
@@ -94,73 +81,22 @@ __device__ __forceinline__ void issue_row(Walk& c, int x, int slot) {
 // the row in `slot` has landed: all but the `younger` operations issued after its LDS-DMA may still be in flight
 __device__ __forceinline__ void wait_row(const Walk& c, int slot) {
   const int younger = c.ops - (int)((((slot >> 2) ? c.gend2 : c.gend) >> (16 * (slot & 3))) & 0xffff);
-  rows::wait_all_but(younger);
+  wait_all_but(younger);
 }
 
 __device__ __forceinline__ void read_row(const Walk& c, int slot, float (&T)[6], float (&w)[6]) {
-  v2 t0, t1, t2, w0, w1, w2;
-  const unsigned sb = kRowB + slot * kSlotB;
-  const unsigned at = c.aT + sb, aw0 = c.aW[0] + sb, aw1 = c.aW[1] + sb, aw2 = c.aW[2] + sb;
-  asm volatile("ds_read_b64 %[t0], %[at]\n\t"
-               "ds_read_b64 %[t1], %[at] offset:8\n\t"
-               "ds_read_b64 %[t2], %[at] offset:16\n\t"
-               "ds_read_b64 %[w0], %[aw0]\n\t"
-               "ds_read_b64 %[w1], %[aw1]\n\t"
-               "ds_read_b64 %[w2], %[aw2]\n\t"
-               "s_waitcnt lgkmcnt(0)"
-               : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2)
-               : [at] "v"(at), [aw0] "v"(aw0), [aw1] "v"(aw1), [aw2] "v"(aw2)
-               : "memory");
-  T[0] = t0.x; T[1] = t0.y; T[2] = t1.x; T[3] = t1.y; T[4] = t2.x; T[5] = t2.y;
-  w[0] = w0.x; w[1] = w0.y; w[2] = w1.x; w[3] = w1.y; w[4] = w2.x; w[5] = w2.y;
+  read_pair(c.L, c.lb + kRowB + slot * kSlotB, T, w);
 }
 
 // six results per lane -> LDS -> sixteen bytes per lane -> HBM (two stores: 64 + 32 quads)
 __device__ __forceinline__ void store_row(Walk& c, const float (&o)[6], int k) {
-  const v2 p0{o[0], o[1]}, p1{o[2], o[3]}, p2{o[4], o[5]};
   vfloat4 q0, q1;
-  asm volatile("ds_write_b64 %[ao], %[p0] offset:%[o0]\n\t"
-               "ds_write_b64 %[ao], %[p1] offset:%[o1]\n\t"
-               "ds_write_b64 %[ao], %[p2] offset:%[o2]\n\t"
-               "ds_read_b128 %[q0], %[r0] offset:%[o0]\n\t"
-               "ds_read_b128 %[q1], %[r1] offset:%[o0]\n\t"
-               "s_waitcnt lgkmcnt(0)"
-               : [q0] "=&v"(q0), [q1] "=&v"(q1)
-               : [ao] "v"(c.aO), [r0] "v"(c.aR0), [r1] "v"(c.aR1), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2),
-                 [o0] "i"(0), [o1] "i"(8), [o2] "i"(16)
-               : "memory");
+  transpose_out(c.L, c.lb, o, q0, q1);
   float* row = c.of + k * kRNx;
   __builtin_nontemporal_store(q0, reinterpret_cast<vfloat4*>(row + 4 * c.lane));
   if (c.lane < 32) __builtin_nontemporal_store(q1, reinterpret_cast<vfloat4*>(row + 256 + 4 * c.lane));
+  order_fence(); // the counted waits need the LDS-DMA and the stores in program order (greb_rows.h)
   c.ops += 2;
-}
-
-// one zonal sweep of a row that does not iterate (time2 = 1), FAST arithmetic: the edge-flux form of greb_device.h
-// (dif_lon_fast) with the lane's six edges e[i] = T(i+1) - T(i), the neighbours' fluxes by wave rotates
-__device__ __forceinline__ void single_sweep_fast(const float (&T)[6], const float (&w)[6], float cs, float (&Tn)[6]) {
-  float A[8], Bx[9]; // A[i] = w(i+1)*e[i], i = 0..7;  Bx[3+i] = w(i)*e[i], i = -3..5
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const float e = (i < 5 ? T[i + 1] : wave_from_next(T[0])) - T[i];
-    A[i] = (i < 5 ? w[i + 1] : wave_from_next(w[0])) * e;
-    Bx[3 + i] = w[i] * e;
-  }
-  A[6] = wave_from_next(A[0]); A[7] = wave_from_next(A[1]);
-  Bx[0] = wave_from_prev(Bx[6]); Bx[1] = wave_from_prev(Bx[7]); Bx[2] = wave_from_prev(Bx[8]);
-  float d[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const float a = A[i] - Bx[3 + i - 1], b = A[i + 1] - Bx[3 + i - 2], g = A[i + 2] - Bx[3 + i - 3];
-    d[i] = cs * (6.f * a + (3.f * b + g));
-    Tn[i] = T[i] + d[i];
-  }
-  // the clamp where(dTxh <= -T1h) dTxh = -0.9*T1h (:715): d <= -T implies fl(T + d) <= 0, so the minimum of the
-  // updated values decides for the whole wavefront whether any point needs the reference's select
-  const float mn = min3f(min3f(Tn[0], Tn[1], Tn[2]), min3f(Tn[3], Tn[4], Tn[5]), Tn[5]);
-  if (__builtin_expect(__any(!(mn > 0.f)), 0)) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Tn[i] = T[i] + ((d[i] <= -T[i]) ? -0.9f * T[i] : d[i]);
-  }
 }
 
 template <bool STRICT>
@@ -218,7 +154,9 @@ __device__ __forceinline__ void row_step(Walk& c, const RowsArgs& a, RowState<ST
 #pragma unroll
     for (int j = 0; j < 6; ++j) T1h[j] = Tw[3 + j];
   } else {
-    single_sweep_fast(cur.T, cur.w, cc * 0.05f, T1h);
+    RowFlux f; // one edge-flux sweep of a row that does not iterate (greb_rows.h)
+    row_flux(cur.T, cur.w, f);
+    dif_sweep_fast(cur.T, f, cc * 0.05f, T1h);
   }
   float o[6];
   if (!STRICT) {
@@ -267,17 +205,9 @@ __global__ __launch_bounds__(64) void dif_rows_kernel(const float* __restrict__ 
   const int k0 = task.rows & 0xff, k1 = (task.rows >> 8) & 0x1ff;
   const size_t fo = (size_t)b * kRNx * ny;
   c.Tf = T1 + fo; c.wf = wz + fo; c.of = dX + fo;
-  c.p2 = c.lane < 32 ? c.Tf + 256 + 4 * c.lane : c.wf + 256 + 4 * (c.lane - 32);
-  const unsigned lb = (unsigned)(size_t)c.lds;
-  c.aT = lb + 24 * c.lane;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const unsigned x = 24 * c.lane + 8 * j;
-    c.aW[j] = lb + (x < 1024 ? 2048 + x : 512 + x);
-  }
-  c.aO = lb + 24 * c.lane;
-  c.aR0 = lb + 16 * c.lane;
-  c.aR1 = lb + (c.lane < 32 ? 1024 + 16 * c.lane : 0);
+  c.p2 = second_halves(c.Tf, c.wf, c.lane);
+  c.lb = (unsigned)(size_t)c.lds;
+  c.L = lane_addr(c.lane);
   c.ops = 0; c.gend = 0; c.gend2 = 0;
   if (dbg & 8) __builtin_amdgcn_s_setprio(2);
   static_assert(kRowsSlots <= 8, "gend, gend2 hold eight 16-bit counters");

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
     float* row = of + r * kNx;
     *reinterpret_cast<vfloat4*>(row + 4 * lane) = q0;
     if (lane < 32) *reinterpret_cast<vfloat4*>(row + 256 + 4 * lane) = q1;
+    order_fence();
     ops += 2;
     GREB_STEP_STAMP(5);
     GREB_STEP_PHASE(3);
