@@ -179,6 +179,11 @@ __device__ __forceinline__ void dif_sweep_fast(const float (&T)[6], const RowFlu
   }
   clamped_update(T, d, Tn);
 }
+// FAST sign split of a wind (src/greb.f90:203-216) as ONE instruction each: max(u, 0) / min(u, 0) instead of a compare
+// and a select (the two differ only in the sign of a zero, which no FAST result keeps; STRICT uses split_m / split_p)
+__device__ __forceinline__ float wind_pos(float u) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(u)); return r; }
+__device__ __forceinline__ float wind_neg(float u) { float r; asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(u)); return r; }
+
 // one sub-cycled advection sweep (adv_lon_sub_fast, :845-851), cs = ccx2/20; last_lane: the lane whose point 3 is
 // longitude xdim-2 (1-based), where the reference's index bug (:881) replaces the 4* and 1* terms
 __device__ __forceinline__ void adv_sweep_fast(const float (&T)[6], const float (&u)[6], const RowFlux& f, float cs,
@@ -192,7 +197,7 @@ __device__ __forceinline__ void adv_sweep_fast(const float (&T)[6], const float 
       const float bug = 10.f * f.A[i] - f.wn0 * (T[4] - f.Tn0);
       ap = last_lane ? bug : ap;
     }
-    d[i] = cs * (-split_p(u[i]) * ap - split_m(u[i]) * am);
+    d[i] = cs * (-wind_neg(u[i]) * ap - wind_pos(u[i]) * am);
   }
   clamped_update(T, d, Tn);
 }

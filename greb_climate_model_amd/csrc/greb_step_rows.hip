@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
         const float gm1 = ww[1][j] * (Tw[1][j] - T0[j]), gp1 = ww[3][j] * (Tw[3][j] - T0[j]);
         const float dm2 = ww[0][j] * (T0[j] - Tw[0][j]), dp2 = ww[4][j] * (T0[j] - Tw[4][j]);
         const float dyd = ccyd * (gm1 + gp1);
-        const float dya = ap * split_p(v[j]) * (dp2 - gp1) - am * split_m(v[j]) * (dm2 - gm1);
+        const float dya = ap * wind_neg(v[j]) * (dp2 - gp1) - am * wind_pos(v[j]) * (dm2 - gm1);
         const float dd = w0[j] * ((Td[j] - T0[j]) + dyd);
         const float da = (Ta[j] - T0[j]) + dya;
         {
