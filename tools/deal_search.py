@@ -24,6 +24,16 @@ DEALS = {  # a leading "P<w>:" puts the polar chains on wave w (default 6); the 
     "q4":    "P6:S0+H S2+F1 T1+F3 T2+F0+F2 S1 T0 F4",
     "q5":    "P6:S0+F0 S2+F1 T1+H T2+F3+F2 S1 T0 F4",
     "q6":    "P6:S0+F0 S2+F1 T1+F3 T0+H+F2 S1 T2 F4",
+    # round 3: every SIMD one ST + one FT + one F1 (888 instructions each, where p6g gives SIMD 0 1 008 and SIMD 3 841), the
+    # chain SIMD H + 2 F1 beside the chains.  Measured (512 members, one gpurun call, p6g = 4 839 cycles per sub-step):
+    # n1 5 002, n5 5 060, n2 5 108, n7 5 155, n4 5 286, n6 5 310 -- equal instruction counts are not equal pipe time
+    # (the ST passes are the packed-heavy ones), and an FT pass as the younger wave of an ST wave takes 4 100-4 650 cycles
+    "n1":    "P6:S0+F0 S1+F1 H+F3+F4 S2+F2 T0 T1 T2",
+    "n2":    "P6:T0+F0 T1+F1 H+F3+F4 T2+F2 S0 S1 S2",
+    "n4":    "P6:S0+T0 S1+T1 H+F0+F1 S2+T2 F2 F3 F4",
+    "n5":    "P6:S0+F0 S1+F1 F3+F4+H S2+F2 T0 T1 T2",
+    "n6":    "P6:S0 S1 H+F3+F4 S2 T0+F0 T1+F1 T2+F2",
+    "n7":    "P6:F0+S0 F1+S1 H+F3+F4 F2+S2 T0 T1 T2",
 }
 
 
