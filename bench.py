@@ -134,7 +134,7 @@ def dry_launch(world, rank, members):
         got = g.finish()
         check = {"ranks_seen": ensemble.ranks_seen("cpu"), "backend": dist.get_backend()}
         if rank == 0:
-            check.update(ensemble.gather_order_check(got[:, 0].double().mean(dim=(1, 2, 3)).numpy()))
+            check.update(ensemble.gather_order_check(got[:, 0].double().mean(dim=(1, 2, 3)).numpy(), block=members))
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": world, "members_per_gpu": members, "partition": parts, **check}))
@@ -242,7 +242,7 @@ def main():
     if world > 1:
         multi = {"ranks_seen": ensemble.ranks_seen("cuda"), "backend": dist.get_backend()}
         if rank == 0:
-            multi.update(ensemble.gather_order_check(gathered[:, -1, :, 0].double().mean(dim=(1, 2)).cpu().numpy()))
+            multi.update(ensemble.gather_order_check(gathered[:, -1, :, 0].double().mean(dim=(1, 2)).cpu().numpy(), block=M))
     finite = bool(torch.isfinite(monthly if gathered is None else gathered).all().item())
     tmean = float((monthly[:, -1, :, 0] if world == 1 else year_bufs[-1][:, 0, :, 0]).mean().item())
 

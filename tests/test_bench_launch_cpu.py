@@ -46,6 +46,11 @@ def test_gather_order_check_finds_a_misplaced_block():
     swapped = np.concatenate([v[8:], v[:8]])  # the two ranks' blocks in each other's slots
     bad = ensemble.gather_order_check(swapped)
     assert bad["gather_verified"] is False and bad["inversions"] == 1
+    assert ensemble.gather_order_check(swapped, block=8)["block_inversions"] == 1
+    # a very fine sweep with rounding noise between neighbours is still in order at the stride the check uses
+    fine = np.linspace(280.0, 1120.0, 4096) + 0.15 * np.sin(np.arange(4096) * 1.7)
+    ok = ensemble.gather_order_check(fine, block=512)
+    assert ok["gather_verified"] is True and ok["inversions"] > 0 and ok["stride"] == 8 and ok["inversions_at_stride"] == 0
     v[3] = np.nan
     assert ensemble.gather_order_check(v)["gather_verified"] is False
 
