@@ -6,8 +6,12 @@
 ! (:162-166), runs flux correction at CO2_ctrl, the control run (-> output/control, after the TF_correct "test
 ! write" of :204-206) and the scenario run (-> output/scenario) through the C ABI (host/greb_c_api.f90).
 ! What log_exp changes in the PROCESSES is the engine's switch set (greb_log_exp_switches, GREB_X_*).
-! The yearly console line carries the global mean and ONE grid point (the engine's ipx/ipy = the first of the
-! original's two hard-wired points, tsmn(48,24+3)); the second point of the original's line is not produced.
+! The yearly console line is the original's (:977): year, global mean, tsmn(48,24+3), tsmn(16,24+14).  The engine's
+! yearly record carries the global mean and ONE point (its ipx/ipy = the first of the two); the second point is the
+! annual mean of the same year's monthly records at (16,38) -- the records the host writes anyway: the day-weighted
+! mean of the twelve monthly means is the mean over the year's 730 steps; it is free of the ~2e-4 K of rounding the
+! original's own running fp32 sum of 730 values of ~300 K carries, so the two agree to that).  The
+! flux-correction lines, which have no monthly records, carry the first point only.
 program greb_host_original
   use iso_c_binding
   use greb_c_api
@@ -24,6 +28,7 @@ program greb_host_original
        mldclim(:,:,:), cldclim(:,:,:), swetclim(:,:,:)
   real(c_float), allocatable :: monthly(:), yearly(:), yflux(:), co2(:), corr(:), start5(:), now5(:)
   integer(c_int) :: rc, x, x_noscn
+  integer, parameter :: jday_mon(12) = (/31,28,31,30,31,30,31,31,30,31,30,31/)   ! src/greb.f90:42
   integer :: n, irec, nrec
   integer(8) :: off
   real :: co2_ctrl, year
@@ -101,7 +106,7 @@ program greb_host_original
      call engine_check(rc, eng, 'greb_engine_run (control)')
      year = 1970.
      do n = 1, time_ctrl
-        print *, year, yearly(2*n-1), yearly(2*n)
+        print *, year, yearly(2*n-1), yearly(2*n), second_point(n)
         year = year + 1
      end do
      do irec = 1, nrec
@@ -134,7 +139,7 @@ program greb_host_original
      call engine_check(rc, eng, 'greb_engine_run (scenario)')
      year = 1940.
      do n = 1, time_scnr
-        print *, year, yearly(2*n-1), yearly(2*n)
+        print *, year, yearly(2*n-1), yearly(2*n), second_point(n)
         year = year + 1
      end do
      open(22, file='output/scenario', access='direct', form='unformatted', recl=4*nx*ny)
@@ -147,6 +152,19 @@ program greb_host_original
   rc = greb_engine_destroy(eng)
 
 contains
+  ! tsmn(16,24+14) - 273.15 of year yr (1-based) of the run whose monthly records are in `monthly`
+  real function second_point(yr)
+    integer, intent(in) :: yr
+    integer :: mm
+    integer(8) :: o
+    double precision :: acc
+    acc = 0.d0
+    do mm = 1, 12
+       o = (int(yr-1, 8)*12 + (mm-1))*5*nx*ny + int(24+14-1, 8)*nx + 16   ! record Tsurf of that month, point (16,38)
+       acc = acc + dble(2*jday_mon(mm))*dble(monthly(o))
+    end do
+    second_point = real(acc/dble(nstep)) - 273.15
+  end function
   ! co2_level of the original (:939-951)
   real function co2_level(le, yr)
     integer, intent(in) :: le

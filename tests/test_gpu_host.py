@@ -93,6 +93,19 @@ def test_original_variant_host(tmp_path, inputs, log_exp):
         assert rms(scen[-1, i], g[k + "_scen_last"][i]) < tol, (log_exp, i)
         assert rms(ctrl[-1, i], g[k + "_ctrl_last"][i]) < tol, (log_exp, i)
         assert np.abs(scen[:, i].astype(np.float64).mean((1, 2)) - g[k + "_scen_stats"][:, i, 0]).max() < 3 * tol
+    # the original's console line (greb.original.model.f90:977): year, global mean, tsmn(48,27), tsmn(16,38).  The
+    # second point is built by the host from the monthly records; the same construction at the FIRST point must give
+    # the engine's own annual mean there (which the reference runs pin), so the second is right by the same rule.
+    rows = np.asarray([[float(x) for x in l.split()] for l in r.stdout.splitlines()
+                       if len(l.split()) == 4 and l.split()[0][:2] in ("19", "20")])
+    assert rows.shape == (1 + 2, 4) and list(rows[1:, 0]) == [1940.0, 1941.0]  # 1 control year + 2 scenario years
+    w = 2.0 * np.asarray((31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31)) / 730.0
+    for y in range(2):
+        ts = scen[12 * y: 12 * y + 12, 0].astype(np.float64)
+        p1 = (w * ts[:, 24 + 3 - 1, 48 - 1]).sum() - 273.15
+        p2 = (w * ts[:, 24 + 14 - 1, 16 - 1]).sum() - 273.15
+        # the engine's own tsmn is, like the original's, a running fp32 sum of 730 values of ~300 K: ~2e-4 K of rounding
+        assert abs(rows[1 + y, 2] - p1) < 5e-4 and abs(rows[1 + y, 3] - p2) < 5e-5, (y, rows[1 + y], p1, p2)
 
 
 def test_plain_c_driver(tmp_path, inputs):

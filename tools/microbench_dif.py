@@ -14,9 +14,12 @@ nx, ny = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (96, 48)
 p = engine.params_default()
 n = batch * nx * ny
 g = torch.Generator(device="cuda").manual_seed(1)
-T1 = 250.0 + 50.0 * torch.rand(n, device="cuda", generator=g)
-wz = 0.3 + 0.7 * torch.rand(n, device="cuda", generator=g)
-dX = torch.empty(n, device="cuda")
+# OFFS=a,b,c: shift the three arrays by that many floats inside their allocations (does the relative alignment of the
+# streams matter?  measured: no)
+offs = [int(x) for x in os.environ.get("OFFS", "0,0,0").split(",")]
+T1 = (250.0 + 50.0 * torch.rand(n + offs[0], device="cuda", generator=g))[offs[0]:]
+wz = (0.3 + 0.7 * torch.rand(n + offs[1], device="cuda", generator=g))[offs[1]:]
+dX = torch.empty(n + offs[2], device="cuda")[offs[2]:]
 st = torch.cuda.current_stream()
 for strict in (False, True):
     # warm-up: after an idle second the first ~10 ms of back-to-back launches run through a power-management transient
