@@ -373,6 +373,30 @@ def test_row_strip_substep_equals_band_kernel_strict(eng_mod, inputs384):
     assert np.isfinite(out[1][0]).all()
 
 
+def test_row_strip_substep_with_experiment_switches(eng_mod, inputs384):
+    """The process switches of the upstream variant (GREB_X_*) on the 384-wide row-strip sub-step: vapour diffused but
+    not advected (the strips give the vapour fields zero wind), no vapour transport, no circulation at all.  FAST on the
+    strips against STRICT on the band kernel with the same switches, one flux-correction year and one scenario year; and
+    each switch must change the climate."""
+    from greb_climate_model_amd import abi
+    p = abi.default_params(ipx=380, ipy=152)
+    base = None
+    for x in (0, abi.X_VAPOR_DIFFUSION_ONLY, abi.X_NO_VAPOR_TRANSPORT, abi.X_NO_CIRCULATION):
+        out = []
+        for strict in (True, False):
+            e = eng_mod.Engine(inputs384, p, strict=strict)
+            e.set_experiment(x)
+            e.flux_correction(1)
+            mon, _ = e.run(1, 680.0)
+            e.close()
+            out.append(mon[0, 0])
+        _check_run(out[1], out[0], f"g384 switches {x}")
+        if x == 0:
+            base = out[1]
+        else:
+            assert rms(out[1][:, 3], base[:, 3]) > 1e-6, x  # humidity responds to every one of these switches
+
+
 @pytest.mark.parametrize("mode", ["strict", "fast", "fast40", "strict_strips"])
 def test_engine_g384_vs_reference(eng_mod, inputs384, mode):
     """BASELINE config 3 in miniature against the REFERENCE compiled at 384x192 (g384_short.npz): 1+2 yr, 2xCO2.
