@@ -65,7 +65,7 @@ namespace greb {
 #define GREB_C6_SUB2 " neg_lo:[0,1] neg_hi:[0,1]\n"
 
 // one sweep: points in set I, result in set O, neighbour flavour F
-#define GREB_C6_SWEEP(I, O, F)                                                                                        \
+#define GREB_C6_SWEEP_BODY(I, O, F, M1, M2, M3)                                                                       \
   "v_pk_add_f32 v[78:79], " GREB_C6_##I##1 ", " GREB_C6_##I##0 GREB_C6_SUB2  /* E3 = (e3, e6) */                      \
   "v_pk_add_f32 v[80:81], " GREB_C6_##I##2 ", " GREB_C6_##I##1 GREB_C6_SUB2  /* E4 = (e4, e7) */                      \
   "v_sub_f32 v82, " GREB_C6_##I##0H ", " GREB_C6_##I##2L "\n"  /* e5 = o3 - o2 */                                     \
@@ -76,6 +76,7 @@ namespace greb {
   "v_mul_f32 v85, %[k30], v78\n"  /* d3  = K30 * e3 */                                                                \
   "v_mul_f32_dpp v86, v81, %[k10]" GREB_C6_PREV_##F  /* d1  = K10 * prev e7 */                                        \
   "v_mul_f32 v87, %[k40], v80\n"  /* d4  = K40 * e4 */                                                                \
+  M1                                                                                                                  \
   "v_pk_mul_f32 v[88:89], %[p20], v[76:77]\n"  /* (d2,d5)  = m0 * (e2,e5) */                                          \
   "v_fmac_f32_dpp v84, v81, %[k01]" GREB_C6_PREV_##F  /* d0 += K01 * prev e7 */                                       \
   "v_fmac_f32 v85, %[k31], v80\n"  /* d3 += K31 * e4 */                                                               \
@@ -86,6 +87,7 @@ namespace greb {
   "v_pk_fma_f32 v[88:89], %[p22], v[80:81], v[88:89]\n"  /* (d2,d5) += m2 * (e4,e7) */                                \
   "v_pk_fma_f32 v[84:85], %[p03], v[78:79], v[84:85]\n"  /* (d0,d3) += m3 * (e3,e6) */                                \
   "v_pk_fma_f32 v[86:87], %[p13], v[80:81], v[86:87]\n"  /* (d1,d4) += m3 * (e4,e7) */                                \
+  M2                                                                                                                  \
   "v_pk_fma_f32 v[88:89], %[p23], v[82:83], v[88:89]\n"  /* (d2,d5) += m3 * (e5,e8) */                                \
   "v_pk_fma_f32 v[84:85], %[p04], v[80:81], v[84:85]\n"  /* (d0,d3) += m4 * (e4,e7) */                                \
   "v_pk_fma_f32 v[86:87], %[p14], v[82:83], v[86:87]\n"  /* (d1,d4) += m4 * (e5,e8) */                                \
@@ -94,14 +96,24 @@ namespace greb {
   "v_pk_fma_f32 v[84:85], %[p05], v[82:83], v[84:85]\n"  /* (d0,d3) += m5 * (e5,e8) */                                \
   "v_fmac_f32 v86, %[k15], v79\n"  /* d1 += K15 * e6 */                                                               \
   "v_fmac_f32_dpp v87, v78, %[k45]" GREB_C6_NEXT_##F  /* d4 += K45 * next e3 */                                       \
+  M3                                                                                                                  \
   "v_fmac_f32 v88, %[k25], v81\n"  /* d2 += K25 * e7 */                                                               \
   "v_fmac_f32_dpp v89, v80, %[k55]" GREB_C6_NEXT_##F  /* d5 += K55 * next e4 */                                       \
   "v_pk_add_f32 " GREB_C6_##O##0 ", " GREB_C6_##I##0 ", v[84:85]\n"                                                   \
   "v_pk_add_f32 " GREB_C6_##O##1 ", " GREB_C6_##I##1 ", v[86:87]\n"                                                   \
-  "v_pk_add_f32 " GREB_C6_##O##2 ", " GREB_C6_##I##2 ", v[88:89]\n"                                                   \
+  "v_pk_add_f32 " GREB_C6_##O##2 ", " GREB_C6_##I##2 ", v[88:89]\n"
+// mn = min of the six updated values: the clamp test of this sweep alone ...
+#define GREB_C6_MIN_FRESH(O)                                                                                          \
   "v_min3_f32 v90, " GREB_C6_##O##0L ", " GREB_C6_##O##1L ", " GREB_C6_##O##2L "\n"                                   \
   "v_min3_f32 v90, v90, " GREB_C6_##O##0H ", " GREB_C6_##O##1H "\n"                                                   \
   "v_min3_f32 v90, v90, " GREB_C6_##O##2H ", " GREB_C6_##O##2H "\n"
+#define GREB_C6_SWEEP(I, O, F) GREB_C6_SWEEP_BODY(I, O, F, , , ) GREB_C6_MIN_FRESH(O)
+// ... or mn carried through the whole chain as the min over every sweep's INPUT points (the same three instructions,
+// but nothing waits for them: they sit between the multiply-adds, one dependent on the other only eleven
+// instructions apart; the caller adds the last sweep's output)
+#define GREB_C6_MIN_IN(I, a, b) "v_min3_f32 v90, v90, " GREB_C6_##I##a ", " GREB_C6_##I##b "\n"
+#define GREB_C6_SWEEP_CARRIED(I, O, F)                                                                                \
+  GREB_C6_SWEEP_BODY(I, O, F, GREB_C6_MIN_IN(I, 0L, 1L), GREB_C6_MIN_IN(I, 2L, 0H), GREB_C6_MIN_IN(I, 1H, 2H))
 
 // The coefficients as the sweep wants them: 12 scalars (the terms that take a DPP operand or stand alone) and 12
 // aligned pairs (K[i][m], K[i+3][m]) for the packed multiply-adds.  Ordinary "v" operands -- the sweep never
@@ -204,6 +216,42 @@ __device__ __forceinline__ int chain_sweeps6(float (&T)[6], const ChainK& c, int
   return rem;
 }
 
+// The common case: ALL `n` sweeps without a test in between, mn carried (GREB_C6_SWEEP_CARRIED).  Per sweep this saves
+// the v_cmp, the wait for vcc and a branch of chain_sweeps6 -- 25 of its 210 cycles on a lone wavefront.  The caller
+// decides afterwards whether any sweep needed the clamp (mn <= 0, over the inputs of every sweep; it adds the last
+// output itself) and if so redoes the chain from its start with chain_sweeps6.
+#define GREB_C6_LOOP_ALL(F)                                                                                           \
+  "s_cmp_eq_u32 %[trips], 0\n"                                                                                        \
+  "s_cbranch_scc1 2f\n"                                                                                               \
+  "1:\n"                                                                                                              \
+  "s_sub_u32 %[trips], %[trips], 1\n" GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_SWEEP_CARRIED(B, A, F)                   \
+  "s_cmp_lg_u32 %[trips], 0\n"                                                                                        \
+  "s_cbranch_scc1 1b\n"                                                                                               \
+  "2:\n"                                                                                                              \
+  "s_cmp_eq_u32 %[odd], 0\n"                                                                                          \
+  "s_cbranch_scc1 3f\n" GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_B_TO_A                                                 \
+  "3:\n"
+#define GREB_C6_CLOBBERS_ALL                                                                                          \
+  "scc", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", \
+      "v86", "v87", "v88", "v89"
+template <bool ROW16>
+__device__ __forceinline__ float chain_sweeps6_all(float (&T)[6], const ChainK& c, int n /* wave-uniform */) {
+  int trips = n >> 1;
+  const int odd = n & 1;
+  float mn = __builtin_inff();
+  if constexpr (ROW16)
+    asm volatile(GREB_C6_LOOP_ALL(R)
+                 : [trips] "+s"(trips), "+{v90}"(mn), GREB_C6_T_OPERANDS(T)
+                 : [odd] "s"(odd), GREB_C6_K_OPERANDS(c)
+                 : GREB_C6_CLOBBERS_ALL);
+  else
+    asm volatile(GREB_C6_LOOP_ALL(W)
+                 : [trips] "+s"(trips), "+{v90}"(mn), GREB_C6_T_OPERANDS(T)
+                 : [odd] "s"(odd), GREB_C6_K_OPERANDS(c)
+                 : GREB_C6_CLOBBERS_ALL);
+  return fminf(fminf(fminf(mn, T[0]), fminf(T[1], T[2])), fminf(fminf(T[3], T[4]), T[5]));
+}
+
 // The same sweep in C++ with its increments handed back (any registers, the compiler's schedule, ~65 instructions):
 // the checked path of chain_run6.  Same operations in the same order as the asm body.
 template <bool ROW16>
@@ -237,14 +285,25 @@ __device__ __forceinline__ void chain_increments6(const float (&o)[6], const Cha
 
 // time2 dependent sweeps with the clamp `where(dTxh <= -T1h) dTxh = -0.9*T1h` (:715 / :907).  d <= -T implies
 // fl(T + d) <= 0 (rounding is monotonic), so the min over the updated values decides whether any lane needs the
-// reference's per-point select; a sweep that does takes the checked path.  time2 must be the same in every lane of
-// the wavefront.
+// reference's per-point select.  The chain is first run WITHOUT a test between its sweeps, the min carried along; if
+// any state of it was <= 0 (rare: the test inputs with zeros and spikes) it is redone from its start by the stop-before
+// loop, whose offending sweeps take the checked path.  time2 must be the same in every lane of the wavefront.
 template <bool ROW16>
 __device__ __forceinline__ void chain_run6(float (&T)[6], const ChainK& c, int time2) {
-  int rem = chain_sweeps6<ROW16>(T, c, __builtin_amdgcn_readfirstlane(time2));
+  const int n = __builtin_amdgcn_readfirstlane(time2);
+  float T0[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) T0[i] = T[i];
+  // min over every state of the chain; a NaN point is skipped by v_min3/fminf -- and by the reference's select
+  // (d <= -T is false for it), so it needs no checked path either
+  const float mn = chain_sweeps6_all<ROW16>(T, c, n);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(mn > 0.f)) == 0, 1)) return;
   // (the rare path is kept out of the common one: written as one loop around the asm statement, the compiler surrounds
   // every chain with its flag and copy bookkeeping, ~25 instructions)
-  while (__builtin_expect(rem > 0, 0)) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) T[i] = T0[i];
+  int rem = chain_sweeps6<ROW16>(T, c, n);
+  while (rem > 0) {
     float d[6];
     chain_increments6<ROW16>(T, c, d);
 #pragma unroll
