@@ -221,33 +221,37 @@ __device__ __forceinline__ int chain_sweeps6(float (&T)[6], const ChainK& c, int
 // decides afterwards whether any sweep needed the clamp (mn <= 0, over the inputs of every sweep; it adds the last
 // output itself) and if so redoes the chain from its start with chain_sweeps6.
 #define GREB_C6_LOOP_ALL(F)                                                                                           \
-  "s_cmp_eq_u32 %[trips], 0\n"                                                                                        \
+  "s_sub_u32 %[trips], %[trips], 1\n" /* scc = borrow: no trip (left) */                                              \
   "s_cbranch_scc1 2f\n"                                                                                               \
   "1:\n"                                                                                                              \
-  "s_sub_u32 %[trips], %[trips], 1\n" GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_SWEEP_CARRIED(B, A, F)                   \
-  "s_cmp_lg_u32 %[trips], 0\n"                                                                                        \
-  "s_cbranch_scc1 1b\n"                                                                                               \
+  "s_sub_u32 %[trips], %[trips], 1\n" /* nothing in the sweeps writes scc */                                          \
+  GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_SWEEP_CARRIED(B, A, F) GREB_C6_SWEEP_CARRIED(A, B, F)                        \
+  GREB_C6_SWEEP_CARRIED(B, A, F)                                                                                      \
+  "s_cbranch_scc0 1b\n"                                                                                               \
   "2:\n"                                                                                                              \
-  "s_cmp_eq_u32 %[odd], 0\n"                                                                                          \
-  "s_cbranch_scc1 3f\n" GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_B_TO_A                                                 \
-  "3:\n"
+  "s_bitcmp0_b32 %[rest], 1\n"                                                                                        \
+  "s_cbranch_scc1 3f\n" GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_SWEEP_CARRIED(B, A, F)                                 \
+  "3:\n"                                                                                                              \
+  "s_bitcmp0_b32 %[rest], 0\n"                                                                                        \
+  "s_cbranch_scc1 4f\n" GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_B_TO_A                                                 \
+  "4:\n"
 #define GREB_C6_CLOBBERS_ALL                                                                                          \
   "scc", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", \
       "v86", "v87", "v88", "v89"
 template <bool ROW16>
 __device__ __forceinline__ float chain_sweeps6_all(float (&T)[6], const ChainK& c, int n /* wave-uniform */) {
-  int trips = n >> 1;
-  const int odd = n & 1;
+  int trips = n >> 2; // four sweeps per trip: the taken branch at the end of a trip costs a lone wavefront ~25 cycles
+  const int rest = n & 3;
   float mn = __builtin_inff();
   if constexpr (ROW16)
     asm volatile(GREB_C6_LOOP_ALL(R)
                  : [trips] "+s"(trips), "+{v90}"(mn), GREB_C6_T_OPERANDS(T)
-                 : [odd] "s"(odd), GREB_C6_K_OPERANDS(c)
+                 : [rest] "s"(rest), GREB_C6_K_OPERANDS(c)
                  : GREB_C6_CLOBBERS_ALL);
   else
     asm volatile(GREB_C6_LOOP_ALL(W)
                  : [trips] "+s"(trips), "+{v90}"(mn), GREB_C6_T_OPERANDS(T)
-                 : [odd] "s"(odd), GREB_C6_K_OPERANDS(c)
+                 : [rest] "s"(rest), GREB_C6_K_OPERANDS(c)
                  : GREB_C6_CLOBBERS_ALL);
   return fminf(fminf(fminf(mn, T[0]), fminf(T[1], T[2])), fminf(fminf(T[3], T[4]), T[5]));
 }
