@@ -216,44 +216,74 @@ __device__ __forceinline__ int chain_sweeps6(float (&T)[6], const ChainK& c, int
   return rem;
 }
 
-// The common case: ALL `n` sweeps without a test in between, mn carried (GREB_C6_SWEEP_CARRIED).  Per sweep this saves
-// the v_cmp, the wait for vcc and a branch of chain_sweeps6 -- 25 of its 210 cycles on a lone wavefront.  The caller
-// decides afterwards whether any sweep needed the clamp (mn <= 0, over the inputs of every sweep; it adds the last
-// output itself) and if so redoes the chain from its start with chain_sweeps6.
-#define GREB_C6_LOOP_ALL(F)                                                                                           \
+// The common case: ALL `n` sweeps without a test in between.  Per sweep this saves the v_cmp, the wait for vcc and a
+// branch of chain_sweeps6 -- 48 of its 210 cycles on a lone wavefront, which issues one vector instruction per 4.0
+// cycles and pays ~30 for a taken branch (hence four or eight sweeps per trip: 162 cycles per sweep with two, 152 with
+// four).  Two flavours of sweep:
+//   CARRIED  mn = min over every sweep's input points (the caller adds the last output); if it ends <= 0 some sweep
+//            needed the clamp and the caller redoes the chain from its start with chain_sweeps6;
+//   PLAIN    no min at all (33 instructions): for chains that cannot reach zero, see chain_stays_positive.
+#define GREB_C6_SWEEP_PLAIN(I, O, F) GREB_C6_SWEEP_BODY(I, O, F, , , )
+#define GREB_C6_PAIR(S, F) GREB_C6_SWEEP_##S(A, B, F) GREB_C6_SWEEP_##S(B, A, F)
+#define GREB_C6_TAIL(S, F, B2, B1) /* the sweeps left after the trips: bits B2 (two) and B1 (one) of `rest` */        \
+  "s_bitcmp0_b32 %[rest], 1\n"                                                                                        \
+  "s_cbranch_scc1 " #B2 "f\n" GREB_C6_PAIR(S, F)                                                                      \
+  #B2 ":\n"                                                                                                           \
+  "s_bitcmp0_b32 %[rest], 0\n"                                                                                        \
+  "s_cbranch_scc1 " #B1 "f\n" GREB_C6_SWEEP_##S(A, B, F) GREB_C6_B_TO_A                                               \
+  #B1 ":\n"
+#define GREB_C6_LOOP4(S, F) /* trips = n >> 2, rest = n & 3 */                                                        \
   "s_sub_u32 %[trips], %[trips], 1\n" /* scc = borrow: no trip (left) */                                              \
   "s_cbranch_scc1 2f\n"                                                                                               \
+  ".p2align 6\n"                                                                                                      \
   "1:\n"                                                                                                              \
   "s_sub_u32 %[trips], %[trips], 1\n" /* nothing in the sweeps writes scc */                                          \
-  GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_SWEEP_CARRIED(B, A, F) GREB_C6_SWEEP_CARRIED(A, B, F)                        \
-  GREB_C6_SWEEP_CARRIED(B, A, F)                                                                                      \
+  GREB_C6_PAIR(S, F) GREB_C6_PAIR(S, F)                                                                               \
+  "s_cbranch_scc0 1b\n"                                                                                               \
+  "2:\n" GREB_C6_TAIL(S, F, 3, 4)
+#define GREB_C6_LOOP8(S, F) /* trips = n >> 3, rest = n & 7 */                                                        \
+  "s_sub_u32 %[trips], %[trips], 1\n"                                                                                 \
+  "s_cbranch_scc1 2f\n"                                                                                               \
+  ".p2align 6\n"                                                                                                      \
+  "1:\n"                                                                                                              \
+  "s_sub_u32 %[trips], %[trips], 1\n"                                                                                 \
+  GREB_C6_PAIR(S, F) GREB_C6_PAIR(S, F) GREB_C6_PAIR(S, F) GREB_C6_PAIR(S, F)                                         \
   "s_cbranch_scc0 1b\n"                                                                                               \
   "2:\n"                                                                                                              \
-  "s_bitcmp0_b32 %[rest], 1\n"                                                                                        \
-  "s_cbranch_scc1 3f\n" GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_SWEEP_CARRIED(B, A, F)                                 \
-  "3:\n"                                                                                                              \
-  "s_bitcmp0_b32 %[rest], 0\n"                                                                                        \
-  "s_cbranch_scc1 4f\n" GREB_C6_SWEEP_CARRIED(A, B, F) GREB_C6_B_TO_A                                                 \
-  "4:\n"
+  "s_bitcmp0_b32 %[rest], 2\n"                                                                                        \
+  "s_cbranch_scc1 5f\n" GREB_C6_PAIR(S, F) GREB_C6_PAIR(S, F)                                                         \
+  "5:\n" GREB_C6_TAIL(S, F, 3, 4)
 #define GREB_C6_CLOBBERS_ALL                                                                                          \
   "scc", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", \
       "v86", "v87", "v88", "v89"
 template <bool ROW16>
 __device__ __forceinline__ float chain_sweeps6_all(float (&T)[6], const ChainK& c, int n /* wave-uniform */) {
-  int trips = n >> 2; // four sweeps per trip: the taken branch at the end of a trip costs a lone wavefront ~25 cycles
-  const int rest = n & 3;
   float mn = __builtin_inff();
-  if constexpr (ROW16)
-    asm volatile(GREB_C6_LOOP_ALL(R)
+  if constexpr (ROW16) { // the fused engine's polar rows: eight sweeps, and an instruction cache shared by eight roles
+    int trips = n >> 2;
+    const int rest = n & 3;
+    asm volatile(GREB_C6_LOOP4(CARRIED, R)
                  : [trips] "+s"(trips), "+{v90}"(mn), GREB_C6_T_OPERANDS(T)
                  : [rest] "s"(rest), GREB_C6_K_OPERANDS(c)
                  : GREB_C6_CLOBBERS_ALL);
-  else
-    asm volatile(GREB_C6_LOOP_ALL(W)
+  } else {
+    int trips = n >> 3;
+    const int rest = n & 7;
+    asm volatile(GREB_C6_LOOP8(CARRIED, W)
                  : [trips] "+s"(trips), "+{v90}"(mn), GREB_C6_T_OPERANDS(T)
                  : [rest] "s"(rest), GREB_C6_K_OPERANDS(c)
                  : GREB_C6_CLOBBERS_ALL);
+  }
   return fminf(fminf(fminf(mn, T[0]), fminf(T[1], T[2])), fminf(fminf(T[3], T[4]), T[5]));
+}
+// ... and without the min (wavefront-sized circles only: the long chains of the 384-wide grid)
+__device__ __forceinline__ void chain_sweeps6_plain(float (&T)[6], const ChainK& c, int n /* wave-uniform */) {
+  int trips = n >> 3;
+  const int rest = n & 7;
+  asm volatile(GREB_C6_LOOP8(PLAIN, W)
+               : [trips] "+s"(trips), GREB_C6_T_OPERANDS(T)
+               : [rest] "s"(rest), GREB_C6_K_OPERANDS(c)
+               : GREB_C6_CLOBBERS_ALL);
 }
 
 // The same sweep in C++ with its increments handed back (any registers, the compiler's schedule, ~65 instructions):
@@ -287,14 +317,64 @@ __device__ __forceinline__ void chain_increments6(const float (&o)[6], const Cha
   });
 }
 
+// A DIFFUSION chain that provably never needs the clamp, so that its sweeps need no test at all.
+// n(c) = T(c) + sum_m K[m] e[c-3+m] with e[j] = T[j+1] - T[j] is sum_j a_j T(c+j) with
+//   a = (-K0, K0-K1, K1-K2, 1+K2-K3, K3-K4, K4-K5, K5),  sum a_j = 1.
+// If every a_j >= 0 (with the smooth weights of the model they are: 6 w(c+1) >= 3 w(c+2) >= w(c+3) >= 0 and the
+// sub-cycling keeps the centre weight up) the sweep is a convex combination: in exact arithmetic the values stay inside
+// [m, M] = [min, max] of the row.  In fp32 (u = 2^-24) a sweep is off by at most u M for the final rounding plus
+// 7 u sum|K| (M - m) for the differences and the multiply-add chain, and sum|K| <= 3 (K3 - K2) <= 2.25 when the centre
+// weight is >= 0.25: less than 17 u M per sweep.  Over N <= 2048 sweeps the minimum falls by less than 2.1e-3 M, so
+// M <= 64 m (margin 7) keeps every state of the chain positive: no point can meet d <= -T.  The tests on K are exact
+// (fp32 comparisons of the stored coefficients, which ARE the map); NaN points are ignored by fminf/fmaxf here as they
+// are by the clamp's comparison.  Rows that fail any of it (vapour over the ice sheets can) take the carried-min loop.
+template <int N>
+__device__ __forceinline__ float chain_row_ror(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + N, 0xf, 0xf, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float chain_wave_extreme(float x) { // over the 64 lanes, the same value in every lane
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+  x = op(x, chain_row_ror<1>(x)); x = op(x, chain_row_ror<2>(x));
+  x = op(x, chain_row_ror<4>(x)); x = op(x, chain_row_ror<8>(x));
+  const int i = __float_as_int(x);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(i, 0)), b = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(i, 32)), d = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+  return op(op(a, b), op(c, d));
+}
+constexpr int kChainPlainMinSweeps = 64, kChainPlainMaxSweeps = 2048; // (the test costs about three sweeps)
+__device__ __forceinline__ bool chain_stays_positive(const float (&T)[6], const float (&K)[6][6], int time2) {
+  if (time2 < kChainPlainMinSweeps || time2 > kChainPlainMaxSweeps) return false;
+  // the smallest of the seven weights a_j, the centre one less its margin (the sign of an fp32 difference is exact);
+  // branch-free: written with && the 42 conditions become 42 exec-mask branches, 2 600 cycles
+  float slack = __builtin_inff();
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    slack = fminf(fminf(slack, -K[i][0]), fminf(K[i][0] - K[i][1], K[i][1] - K[i][2]));
+    slack = fminf(fminf(slack, K[i][5]), fminf(K[i][3] - K[i][4], K[i][4] - K[i][5]));
+    slack = fminf(slack, (0.75f + K[i][2]) - K[i][3]);
+  }
+  float lo = fminf(fminf(fminf(T[0], T[1]), fminf(T[2], T[3])), fminf(T[4], T[5]));
+  lo = fminf(lo, slack >= 0.f ? __builtin_inff() : -1.f); // a lane whose coefficients fail vetoes through the minimum
+  lo = chain_wave_extreme<false>(lo);
+  const float hi = chain_wave_extreme<true>(fmaxf(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])), fmaxf(T[4], T[5])));
+  return lo >= 1e-30f && hi <= 64.f * lo;
+}
+
 // time2 dependent sweeps with the clamp `where(dTxh <= -T1h) dTxh = -0.9*T1h` (:715 / :907).  d <= -T implies
 // fl(T + d) <= 0 (rounding is monotonic), so the min over the updated values decides whether any lane needs the
 // reference's per-point select.  The chain is first run WITHOUT a test between its sweeps, the min carried along; if
 // any state of it was <= 0 (rare: the test inputs with zeros and spikes) it is redone from its start by the stop-before
 // loop, whose offending sweeps take the checked path.  time2 must be the same in every lane of the wavefront.
 template <bool ROW16>
-__device__ __forceinline__ void chain_run6(float (&T)[6], const ChainK& c, int time2) {
+__device__ __forceinline__ void chain_run6(float (&T)[6], const ChainK& c, int time2, bool positive = false) {
   const int n = __builtin_amdgcn_readfirstlane(time2);
+  if constexpr (!ROW16) {
+    if (positive) { // chain_stays_positive: wave-uniform
+      chain_sweeps6_plain(T, c, n);
+      return;
+    }
+  }
   float T0[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) T0[i] = T[i];

@@ -206,7 +206,8 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     step_tasks = it->second.first; n_step_tasks = it->second.second;
   }
   HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
-  for (int s = 0; s < kNT; ++s) {
+  static const int steps = tuning_int("GREB_DEBUG_NSTEPS", kNT); // -DGREB_TUNING builds only: a short stretch for counter passes
+  for (int s = 0; s < steps; ++s) {
     const long long it = a.it0 + s;
     const int ityr = (int)((it - 1) % kNT) + 1;
     const size_t off = (size_t)(ityr - 1) * np;

@@ -302,7 +302,8 @@ __device__ __forceinline__ void chain_window(float (&T)[P + 6], const float (&w)
     float own[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) own[i] = T[3 + i];
-    chain_run6<false>(own, chain_pack(K), time2);
+    const bool positive = !is_adv && chain_stays_positive(own, K, time2);
+    chain_run6<false>(own, chain_pack(K), time2, positive);
 #pragma unroll
     for (int i = 0; i < 6; ++i) T[3 + i] = own[i];
   }

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
 
 int step_row_cost(const RowTables& t, int k) {
   const int d = t.dif_time2[k], a = t.adv_time2[k];
-  return 330 + (d > 1 ? 110 + 36 * d : 0) + (a > 1 ? 110 + 36 * a : 0);
+  static const int row = tuning_int("GREB_STEP_ROWCOST", 330); // -DGREB_TUNING builds only
+  return row + (d > 1 ? 110 + 36 * d : 0) + (a > 1 ? 110 + 36 * a : 0);
 }
 
 } // namespace
@@ -311,6 +312,25 @@ void step_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members,
     all = chains;
     all.insert(all.end(), streams.begin(), streams.end());
     std::stable_sort(all.begin(), all.end(), [](const T& x, const T& y) { return x.cost > y.cost; });
+  }
+  // the cheapest strips -- the last `tail` per cent of the launch's cost -- are cut in halves, `tail2` per cent in quarters
+  static const int tail = tuning_int("GREB_STEP_TAIL", 0), tail2 = tuning_int("GREB_STEP_TAIL2", 0);
+  if (tail > 0) {
+    long long total = 0, acc = 0;
+    for (const T& x : all) total += x.cost;
+    std::vector<T> cut;
+    for (const T& x : all) {
+      acc += x.cost;
+      const int parts = acc > total - total * tail2 / 100 ? 4 : (acc > total - total * tail / 100 ? 2 : 1);
+      const int rows = x.k1 - x.k0, n = std::min(parts, std::max(1, rows / 2));
+      for (int i = 0; i < n; ++i) {
+        T y = x;
+        y.k0 = x.k0 + rows * i / n; y.k1 = x.k0 + rows * (i + 1) / n; y.cost = x.cost * (y.k1 - y.k0) / rows;
+        cut.push_back(y);
+      }
+    }
+    std::stable_sort(cut.begin(), cut.end(), [](const T& x, const T& y) { return x.cost > y.cost; });
+    all.swap(cut);
   }
   tasks.clear();
   tasks.reserve(all.size());

@@ -18,7 +18,8 @@ st = os.path.join(d, "kt", "run_kernel_stats.csv")
 if os.path.exists(st):
     for r in csv.DictReader(open(st)):
         dur[r["Name"]] = (float(r["AverageNs"]) * 1e-3, float(r["MinNs"]) * 1e-3, float(r["MaxNs"]) * 1e-3, int(r["Calls"]))
-ALGO = 12.0 * 1024 * 384 * 192
+NF = int(os.environ.get("FIELDS", 1024))  # fields per launch (tools/prof_step.sh: 2 per member)
+ALGO = 12.0 * NF * 384 * 192
 for k in sorted(cnt):
     if "greb" not in k:
         continue
@@ -38,7 +39,7 @@ for k in sorted(cnt):
         print(f"   busy cycles per XCD      {cyc:.4g} (GRBM_GUI_ACTIVE / 8)")
         print(f"   VALU active              {100 * c['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * cyc):.1f} % of the SIMD-cycles (SQ_ACTIVE_INST_VALU x 4 / (1 024 SIMDs x cycles))")
         if "SQ_INSTS_VALU" in c:
-            print(f"   VALU instructions        {c['SQ_INSTS_VALU'] / 1024:.0f} per field; one per SIMD every {1024 * cyc / c['SQ_INSTS_VALU']:.2f} cycles")
+            print(f"   VALU instructions        {c['SQ_INSTS_VALU'] / NF:.0f} per field; one per SIMD every {1024 * cyc / c['SQ_INSTS_VALU']:.2f} cycles")
     if "SQ_WAVE_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         cyc = c["GRBM_GUI_ACTIVE"] / 8
         print(f"   waves resident           {c['SQ_WAVE_CYCLES'] * 4 / cyc / 1024:.2f} per SIMD on average (SQ_WAVE_CYCLES x 4 / cycles / 1 024); {c.get('SQ_WAVES', 0):.0f} waves launched")
