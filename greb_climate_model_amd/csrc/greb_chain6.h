@@ -253,6 +253,14 @@ __device__ __forceinline__ int chain_sweeps6(float (&T)[6], const ChainK& c, int
   "s_bitcmp0_b32 %[rest], 2\n"                                                                                        \
   "s_cbranch_scc1 5f\n" GREB_C6_PAIR(S, F) GREB_C6_PAIR(S, F)                                                         \
   "5:\n" GREB_C6_TAIL(S, F, 3, 4)
+#ifndef GREB_C6_W_SHIFT // sweeps per trip of the wavefront-sized circles: 2^3 (A/B: -DGREB_C6_W_SHIFT=2)
+#define GREB_C6_W_SHIFT 3
+#endif
+#if GREB_C6_W_SHIFT == 3
+#define GREB_C6_W_LOOP GREB_C6_LOOP8
+#else
+#define GREB_C6_W_LOOP GREB_C6_LOOP4
+#endif
 #define GREB_C6_CLOBBERS_ALL                                                                                          \
   "scc", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", \
       "v86", "v87", "v88", "v89"
@@ -267,9 +275,9 @@ __device__ __forceinline__ float chain_sweeps6_all(float (&T)[6], const ChainK& 
                  : [rest] "s"(rest), GREB_C6_K_OPERANDS(c)
                  : GREB_C6_CLOBBERS_ALL);
   } else {
-    int trips = n >> 3;
-    const int rest = n & 7;
-    asm volatile(GREB_C6_LOOP8(CARRIED, W)
+    int trips = n >> GREB_C6_W_SHIFT;
+    const int rest = n & ((1 << GREB_C6_W_SHIFT) - 1);
+    asm volatile(GREB_C6_W_LOOP(CARRIED, W)
                  : [trips] "+s"(trips), "+{v90}"(mn), GREB_C6_T_OPERANDS(T)
                  : [rest] "s"(rest), GREB_C6_K_OPERANDS(c)
                  : GREB_C6_CLOBBERS_ALL);
@@ -278,9 +286,9 @@ __device__ __forceinline__ float chain_sweeps6_all(float (&T)[6], const ChainK& 
 }
 // ... and without the min (wavefront-sized circles only: the long chains of the 384-wide grid)
 __device__ __forceinline__ void chain_sweeps6_plain(float (&T)[6], const ChainK& c, int n /* wave-uniform */) {
-  int trips = n >> 3;
-  const int rest = n & 7;
-  asm volatile(GREB_C6_LOOP8(PLAIN, W)
+  int trips = n >> GREB_C6_W_SHIFT;
+  const int rest = n & ((1 << GREB_C6_W_SHIFT) - 1);
+  asm volatile(GREB_C6_W_LOOP(PLAIN, W)
                : [trips] "+s"(trips), GREB_C6_T_OPERANDS(T)
                : [rest] "s"(rest), GREB_C6_K_OPERANDS(c)
                : GREB_C6_CLOBBERS_ALL);

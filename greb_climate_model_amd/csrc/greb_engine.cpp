@@ -200,7 +200,9 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     auto it = e->step_tasks.find(nrun);
     if (it == e->step_tasks.end()) {
       RowsTask* dev = nullptr; int n = 0;
-      HIP_TRY(e, step_rows_make_tasks(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, &dev, &n));
+      int cus = 0;
+      HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+      HIP_TRY(e, step_rows_make_tasks(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, cus * kStepRowsSlotsPerCu, &dev, &n));
       it = e->step_tasks.emplace(nrun, std::make_pair(dev, n)).first;
     }
     step_tasks = it->second.first; n_step_tasks = it->second.second;
@@ -215,7 +217,7 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     for (int tt = 0; tt < a.nsub; ++tt) {
       if (rows)
         HIP_TRY(e, launch_substep_rows(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, step_tasks,
-                                       n_step_tasks, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
+                                       n_step_tasks, 2 * nrun, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
       else
         HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
                                         e->ny, nrun, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
@@ -695,7 +697,7 @@ int greb_substep_launch_order(const greb_params* p, int nx, int ny, int n_member
   for (int m = 0; m < n_members; ++m) { compute_row_tables(*p, kappa ? kappa[m] : p->kappa, nx, ny, tabs[m]); idx[m] = m; }
   if (!step_rows_supported(tabs.data(), n_members, nx, ny)) return 0;
   std::vector<RowsTask> tasks;
-  step_rows_tasks(tabs.data(), idx.data(), n_members, ny, tasks);
+  step_rows_tasks(tabs.data(), idx.data(), n_members, ny, 256 * kStepRowsSlotsPerCu, tasks); // an MI355X: 256 CUs
   for (size_t i = 0; i < tasks.size() && (int)i < capacity; ++i) {
     field[i] = tasks[i].field; k0[i] = tasks[i].rows & 0xff; k1[i] = (tasks[i].rows >> 8) & 0x1ff;
   }

@@ -99,12 +99,14 @@ hipError_t launch_diffusion_rows(const float* T1, const float* wz, float* dX, co
                                  bool strict, hipStream_t s);
 // greb_step_rows.hip: the engine's circulation sub-step on a 384-wide grid as wavefront-sized row strips
 bool step_rows_supported(const RowTables* tabs, int n_tabs, int nx, int ny);
-void step_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members, int ny, std::vector<RowsTask>& tasks);
+constexpr int kStepRowsSlotsPerCu = 8; // wavefronts of the sub-step kernel a CU holds (187 VGPRs, 19.5 KB of LDS each)
+void step_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members, int ny, int n_slots,
+                     std::vector<RowsTask>& tasks);
 hipError_t step_rows_make_tasks(const RowTables* tabs_host, const int* tab_index_host, int n_members, int ny,
-                                RowsTask** dev, int* n);
+                                int n_slots, RowsTask** dev, int* n);
 hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
                                const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, int n_tasks,
-                               int ny, bool strict, hipStream_t s, bool calm_vapor);
+                               int n_fields, int ny, bool strict, hipStream_t s, bool calm_vapor);
 hipError_t launch_advection(const float* T1, const float* wz, const float* u, const float* v, float* dX,
                             const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s);
 // 24 sub-steps; 96x48 uses the fused LDS loop of the engine, other grids launch per sub-step

@@ -40,7 +40,9 @@ struct StepArgs {
   const int* tab_index;    // [n_members]
   const RowsTask* tasks;   // field = 2 * member + tracer
   int ny, calm_odd;        // calm_odd: the vapour fields see zero wind (greb.original.model.f90:560-564)
+  int chains_first;        // who issues first where a chain and a streaming strip share a SIMD (launch_substep_rows)
   unsigned long long* stamps; // -DGREB_TUNING builds only (null otherwise): s_memtime stamps of task 0
+  unsigned long long* timeline; // -DGREB_TUNING builds only: [task][start, end] in s_memrealtime ticks (100 MHz) + [2 n]: hw id
 };
 #ifdef GREB_TUNING
 #define GREB_STEP_STAMP(i) if (a.stamps && blockIdx.x == 0 && r == k0 && lane == 0) a.stamps[i] = __builtin_amdgcn_s_memtime()
@@ -64,6 +66,14 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
   const RowsTask task = a.tasks[blockIdx.x];
   const int fld = task.field;
   if (fld < 0) return;
+#ifdef GREB_TUNING
+  if (a.timeline && threadIdx.x == 0) {
+    a.timeline[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); // wave, SIMD, CU, SE ids
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.timeline[2 * gridDim.x + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   const int k0 = task.rows & 0xff, k1 = (task.rows >> 8) & 0x1ff, ny = a.ny;
   const unsigned lane = threadIdx.x;
   const int member = fld >> 1, tracer = fld & 1;
@@ -78,6 +88,7 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
   const unsigned lb = (unsigned)(size_t)lds;
   const bool calm = a.calm_odd && tracer;
   const bool last_lane = lane == 63;
+  if (!a.chains_first) __builtin_amdgcn_s_setprio(2); // streaming rows ahead of the chains (which drop to 0 while they sweep)
   int ops = 0;
   unsigned long long gT = 0, gU = 0; // 16 bits per slot: `ops` right after the slot's LDS-DMA was issued
   auto issue_T = [&](int row) {
@@ -182,17 +193,20 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
       for (int j = 0; j < 12; ++j) T2[j] = Tc[j];
       GREB_STEP_STAMP(2);
       if (STRICT || t2d > 1) {
-        chain_window<STRICT, 6>(Tc, wc, u0, ccd, t2d, false, (int)lane);
+        if (!a.chains_first) __builtin_amdgcn_s_setprio(0);
+        chain_window<STRICT, 6>(Tc, wc, u0, ccd, t2d, false, (int)lane, a.chains_first != 0);
 #pragma unroll
         for (int j = 0; j < 6; ++j) Td[j] = Tc[3 + j];
       }
       GREB_STEP_STAMP(3);
       if (STRICT || t2a > 1) {
-        chain_window<STRICT, 6>(T2, wc, u, cca, t2a, true, (int)lane);
+        if (!a.chains_first) __builtin_amdgcn_s_setprio(0);
+        chain_window<STRICT, 6>(T2, wc, u, cca, t2a, true, (int)lane, a.chains_first != 0);
 #pragma unroll
         for (int j = 0; j < 6; ++j) Ta[j] = T2[3 + j];
       }
     }
+    if (!a.chains_first) __builtin_amdgcn_s_setprio(2);
     if (!STRICT && (t2d <= 1 || t2a <= 1)) {
       RowFlux f;
       row_flux(T0, w0, f);
@@ -252,13 +266,24 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
     a.stamps[9] = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < 4; ++i) a.stamps[12 + i] = phase_sum[i];
   }
+  if (a.timeline && threadIdx.x == 0) a.timeline[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
-int step_row_cost(const RowTables& t, int k) {
+// What a row costs, in cycles (tools/stamp_step_rows.py, tools/step_timeline.py; profiles/r03_g384_substep_*):
+//   issue  the issue slots it takes on its SIMD -- one instruction per 4 cycles, shared by the SIMD's two wavefronts:
+//          ~480 instructions for a streamed row, 36 per chain sweep (33 without the clamp minimum), ~210 to set a chain up;
+//   wall   what the row takes a wavefront that has the SIMD to itself: a streamed row waits for memory (3 500 cycles for
+//          1 900 of issue -- 2 200 as it shares the SIMD, the figure used), a chain never waits.
+// Two strips on one SIMD end after max(their walls, the sum of their issues): measured 94 000 cycles for a polar strip of
+// 63 500 beside a 16-row streaming strip (30 400 of issue), 61 000-70 000 for two such streaming strips.
+struct RowCost { int issue, wall; };
+constexpr int kRowIssue = 2200, kRowWall = 3500, kSweepCycles = 147, kChainSetupCycles = 850, kFillIssue = 700, kFillWall = 3800;
+RowCost step_row_cost(const RowTables& t, int k) {
   const int d = t.dif_time2[k], a = t.adv_time2[k];
-  static const int row = tuning_int("GREB_STEP_ROWCOST", 330); // -DGREB_TUNING builds only
-  return row + (d > 1 ? 110 + 36 * d : 0) + (a > 1 ? 110 + 36 * a : 0);
+  static const int row_issue = tuning_int("GREB_STEP_ROWCOST", kRowIssue); // -DGREB_TUNING builds only
+  const int chains = (d > 1 ? kChainSetupCycles + kSweepCycles * d : 0) + (a > 1 ? kChainSetupCycles + kSweepCycles * a : 0);
+  return {row_issue + chains, kRowWall + chains};
 }
 
 } // namespace
@@ -271,66 +296,74 @@ bool step_rows_supported(const RowTables* tabs, int n_tabs, int nx, int ny) {
   return true;
 }
 
-// The launch order of one sub-step: per field the rows are cut into strips of about `target` instructions (a row is never
-// split), the strips of all fields are launched dearest first -- the long polar chains start in the first microsecond
-// and set the length of the launch, everything else fills the other SIMDs beside them.  The target follows the member
-// count: few members are cut fine (every CU gets something to do), many members coarse (fewer halo rows re-read).
-void step_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members, int ny, std::vector<RowsTask>& tasks) {
-  struct T { int field, k0, k1, cost, chain; };
-  std::vector<T> chains, streams;
-  const int n_fields = 2 * n_members;
-  static const int forced = tuning_int("GREB_STEP_TARGET", 0); // -DGREB_TUNING builds only
-  const int target = forced ? forced : (n_fields <= 8 ? 1400 : (n_fields <= 48 ? 2400 : 6000));
-  for (int m = 0; m < n_members; ++m) {
-    const RowTables& t = tabs[tab_index[m]];
-    int acc = 0, start = 0, chain = 0;
-    std::vector<T> mine;
+// The launch order of one sub-step.  The chip has slots / 2 SIMDs with two wavefront slots each (187 VGPRs, 19.5 KB of
+// LDS per wavefront); workgroup i of a launch lands on SIMD i mod (slots / 2), so tasks i and i + slots / 2 share one.
+// A launch is as long as its longest SIMD, and a task started late -- because there are more tasks than slots -- runs
+// its full length after the others are done (62 members as 2 388 tasks for 2 048 slots: 40 us, 13 of them for the 340
+// late strips).  So ONE round: the rows of all fields are cut into at most `n_slots` strips such that a SIMD's pair ends
+// after S cycles -- each strip at most S / 2 of issue and S of wall (RowCost) -- with S the smallest that fits, but no
+// less than the dearest row's wall (the 232-sweep polar row: few fields gain nothing from strips that end before it).
+// With n tasks for n_simd SIMDs, n - n_simd SIMDs hold a pair: the strips with the most issue run alone, the others are
+// paired dearest with cheapest (two chain strips on one SIMD -- both issue without a pause -- take twice as long each).
+void step_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members, int ny, int n_slots,
+                     std::vector<RowsTask>& tasks) {
+  struct T { int field, k0, k1; long long issue, wall; };
+  static const int forced = tuning_int("GREB_STEP_TARGET", 0);        // -DGREB_TUNING builds only: S in cycles
+  static const int issue_pct = tuning_int("GREB_STEP_ISSUE_PCT", 54); // ... a strip's share of S in issue
+  static const int wall_pct = tuning_int("GREB_STEP_WALL_PCT", 70);   // ... and in wall time (measured: 1 member 19.1 us per launch at 85-100, 18.5 at 60-70)
+  const int n_simd = std::max(1, n_slots / 2);
+  long long total = 0, dearest = 0;
+  for (int m = 0; m < n_members; ++m)
     for (int k = 0; k < ny; ++k) {
-      const int c = step_row_cost(t, k);
-      if (acc > 0 && acc + c > target) { mine.push_back({0, start, k, acc, chain}); start = k; acc = 0; chain = 0; }
-      acc += c;
-      chain |= t.dif_time2[k] > 1 || t.adv_time2[k] > 1;
+      const RowCost c = step_row_cost(tabs[tab_index[m]], k);
+      total += 2 * c.issue;
+      dearest = std::max<long long>(dearest, c.wall);
     }
-    mine.push_back({0, start, ny, acc, chain});
-    for (int tr = 0; tr < 2; ++tr)
-      for (T x : mine) { x.field = 2 * m + tr; (x.chain ? chains : streams).push_back(x); }
-  }
-  // chain strips dearest first, and a streaming strip after every chain strip: a SIMD holds two wavefronts of this
-  // kernel, and two chains on one SIMD slow each other (a sweep occupies the pipe for ~130 of its 210 cycles) while the
-  // streaming strips would only start when the chains are over
-  std::stable_sort(chains.begin(), chains.end(), [](const T& x, const T& y) { return x.cost > y.cost; });
-  static const int interleave = tuning_int("GREB_STEP_INTERLEAVE", 0);
+  long long S = std::max(total / n_simd, dearest + kFillWall);
+  if (forced) S = forced;
   std::vector<T> all;
-  all.reserve(chains.size() + streams.size());
-  if (interleave) {
-    size_t i = 0, j = 0;
-    while (i < chains.size() || j < streams.size()) {
-      if (i < chains.size()) all.push_back(chains[i++]);
-      if (j < streams.size()) all.push_back(streams[j++]);
-    }
-  } else { // every strip by cost, dearest first (measured 40.3-41.3 us per launch at 62 members against 42.2-45.9)
-    all = chains;
-    all.insert(all.end(), streams.begin(), streams.end());
-    std::stable_sort(all.begin(), all.end(), [](const T& x, const T& y) { return x.cost > y.cost; });
-  }
-  // the cheapest strips -- the last `tail` per cent of the launch's cost -- are cut in halves, `tail2` per cent in quarters
-  static const int tail = tuning_int("GREB_STEP_TAIL", 0), tail2 = tuning_int("GREB_STEP_TAIL2", 0);
-  if (tail > 0) {
-    long long total = 0, acc = 0;
-    for (const T& x : all) total += x.cost;
-    std::vector<T> cut;
-    for (const T& x : all) {
-      acc += x.cost;
-      const int parts = acc > total - total * tail2 / 100 ? 4 : (acc > total - total * tail / 100 ? 2 : 1);
-      const int rows = x.k1 - x.k0, n = std::min(parts, std::max(1, rows / 2));
-      for (int i = 0; i < n; ++i) {
-        T y = x;
-        y.k0 = x.k0 + rows * i / n; y.k1 = x.k0 + rows * (i + 1) / n; y.cost = x.cost * (y.k1 - y.k0) / rows;
-        cut.push_back(y);
+  for (int pass = 0; pass < 96; ++pass) {
+    const long long cap_issue = S * issue_pct / 100, cap_wall = S * wall_pct / 100;
+    all.clear();
+    for (int m = 0; m < n_members; ++m) {
+      const RowTables& t = tabs[tab_index[m]];
+      // this member's fields: as few strips as the two caps allow, cut where the cumulative issue crosses equal shares
+      // (a greedy cut leaves every strip some way below its cap: more strips, or a larger S, than needed)
+      long long fi = 0, fw = 0;
+      for (int k = 0; k < ny; ++k) { const RowCost c = step_row_cost(t, k); fi += c.issue; fw += c.wall; }
+      const long long ci = std::max<long long>(1, cap_issue - kFillIssue), cw = std::max<long long>(1, cap_wall - kFillWall);
+      const int n = (int)std::min<long long>(ny, std::max((fi + ci - 1) / ci, (fw + cw - 1) / cw));
+      std::vector<T> mine;
+      long long acc = 0, issue = kFillIssue, wall = kFillWall;
+      int start = 0, cut = 1;
+      for (int k = 0; k < ny; ++k) {
+        const RowCost c = step_row_cost(t, k);
+        // the share boundary cut * fi / n lies nearer the start of row k than its end: close the strip before it
+        if (k > start && cut < n && 2 * n * acc + (long long)n * c.issue >= 2 * fi * cut) {
+          mine.push_back({0, start, k, issue, wall});
+          start = k; issue = kFillIssue; wall = kFillWall;
+          while (cut < n && 2 * n * acc + (long long)n * c.issue >= 2 * fi * cut) ++cut; // (a dear row may span shares)
+        }
+        acc += c.issue; issue += c.issue; wall += c.wall;
       }
+      mine.push_back({0, start, ny, issue, wall});
+      for (int tr = 0; tr < 2; ++tr)
+        for (T x : mine) { x.field = 2 * m + tr; all.push_back(x); }
     }
-    std::stable_sort(cut.begin(), cut.end(), [](const T& x, const T& y) { return x.cost > y.cost; });
-    all.swap(cut);
+    if (forced || (int)all.size() <= 2 * n_simd) break;
+    S += S / 40;
+  }
+  std::stable_sort(all.begin(), all.end(), [](const T& x, const T& y) { return x.issue > y.issue; });
+  const int n_all = (int)all.size();
+  if (n_all > n_simd && n_all <= 2 * n_simd) {
+    const int m = n_all - n_simd, alone = n_simd - m; // m SIMDs hold a pair
+    std::vector<T> order((size_t)n_all);
+    for (int j = 0; j < m; ++j) {
+      order[(size_t)j] = all[(size_t)(alone + j)];                // the dearer of pair j ...
+      order[(size_t)(n_simd + j)] = all[(size_t)(n_all - 1 - j)]; // ... and the cheapest left
+    }
+    for (int j = 0; j < alone; ++j) order[(size_t)(m + j)] = all[(size_t)j];
+    all.swap(order);
   }
   tasks.clear();
   tasks.reserve(all.size());
@@ -339,9 +372,9 @@ void step_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members,
 
 // the launch order on the device (owned by the caller: the engine keeps one per member count and frees it with itself)
 hipError_t step_rows_make_tasks(const RowTables* tabs_host, const int* tab_index_host, int n_members, int ny,
-                                RowsTask** dev, int* n) {
+                                int n_slots, RowsTask** dev, int* n) {
   std::vector<RowsTask> host;
-  step_rows_tasks(tabs_host, tab_index_host, n_members, ny, host);
+  step_rows_tasks(tabs_host, tab_index_host, n_members, ny, n_slots, host);
   hipError_t e = hipMalloc(dev, host.size() * sizeof(RowsTask));
   if (e != hipSuccess) return e;
   if ((e = hipMemcpy(*dev, host.data(), host.size() * sizeof(RowsTask), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -357,6 +390,21 @@ hipError_t step_rows_make_tasks(const RowTables* tabs_host, const int* tab_index
 // diagnostic builds only: six s_memtime stamps of the dearest task of the last launch (tools/stamp_step_rows.py):
 // loop entry, own row + wind landed, before the diffusion chain, before the advection chain, after it, row stored
 static unsigned long long* g_step_stamps = nullptr;
+static unsigned long long* g_step_timeline = nullptr;
+static int g_step_timeline_cap = 0;
+// [task][start, end] of the LAST launch in 100 MHz ticks, then one hardware id per task; out == null arms it for `capacity` tasks
+extern "C" int greb_tuning_step_timeline(unsigned long long* out, int capacity) {
+  if (!out) {
+    if (g_step_timeline) (void)hipFree(g_step_timeline);
+    g_step_timeline = nullptr; g_step_timeline_cap = 0;
+    if (capacity <= 0) return 0;
+    if (hipMalloc(&g_step_timeline, (size_t)capacity * 3 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    g_step_timeline_cap = capacity;
+    return hipMemset(g_step_timeline, 0, (size_t)capacity * 3 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+  }
+  if (!g_step_timeline || capacity > g_step_timeline_cap) return -1;
+  return hipMemcpy(out, g_step_timeline, (size_t)capacity * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 extern "C" int greb_tuning_step_stamps(unsigned long long* out6) {
   if (!out6) { // arm
     if (!g_step_stamps && hipMalloc(&g_step_stamps, 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
@@ -370,10 +418,20 @@ extern "C" int greb_tuning_step_stamps(unsigned long long* out6) {
 
 hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
                                const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, int n_tasks,
-                               int ny, bool strict, hipStream_t s, bool calm_vapor) {
-  StepArgs a{X, W2, u, v, Xnew, tabs_dev, tab_index_dev, tasks, ny, calm_vapor ? 1 : 0, nullptr};
+                               int n_fields, int ny, bool strict, hipStream_t s, bool calm_vapor) {
+  // A chain never waits, so at equal priority (it is the older wavefront) it takes every issue slot of its SIMD and the
+  // streaming strip beside it -- which needs few slots but a long time, it waits for memory -- stands still until the
+  // chain is over.  Where SIMDs are shared (more tasks than SIMDs) the streaming rows therefore issue first and the
+  // chains fill what is left: the pair ends after max(wall, sum of issues) instead of their sum.  With a SIMD per task
+  // (few fields) the long chains keep their raised priority.
+  static const int chain_fields = tuning_int("GREB_STEP_PRIO_FIELDS", -1); // -DGREB_TUNING builds only
+  int cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  const bool chains_first = chain_fields >= 0 ? n_fields <= chain_fields : n_tasks <= cus * 4;
+  StepArgs a{X, W2, u, v, Xnew, tabs_dev, tab_index_dev, tasks, ny, calm_vapor ? 1 : 0, chains_first ? 1 : 0, nullptr, nullptr};
 #ifdef GREB_TUNING
   a.stamps = g_step_stamps;
+  a.timeline = n_tasks <= g_step_timeline_cap ? g_step_timeline : nullptr;
 #endif
   auto kern = strict ? step_rows_kernel<true> : step_rows_kernel<false>;
   hipLaunchKernelGGL(kern, dim3((unsigned)n_tasks), dim3(64), kStepLdsB, s, a);

@@ -46,11 +46,12 @@ def test_other_grids_keep_the_band_kernel():
         assert len(engine.diffusion_launch_order(abi.default_params(), nx, ny, 4)[0]) == 0
 
 
-@pytest.mark.parametrize("n_members", [1, 3, 8, 40])
-def test_substep_order_is_a_partition_and_dearest_first(n_members):
+@pytest.mark.parametrize("n_members", [1, 3, 8, 40, 62])
+def test_substep_order_is_a_partition_in_one_round(n_members):
     """The engine's row-strip sub-step (greb_step_rows.hip: step_rows_tasks): every row of every (member, tracer) field
-    exactly once -- with per-member diffusivities, i.e. different sub-cycle tables per member -- and the strips that hold
-    the long polar chains at the head of the launch."""
+    exactly once -- with per-member diffusivities, i.e. different sub-cycle tables per member --, never more tasks than
+    the chip has wavefront slots (2 048: a task started late ends the launch late), and the two tasks that share a SIMD
+    (i and i + 1 024) never both hold a 232-sweep polar row; with a SIMD per task the dearest strips lead the launch."""
     p = abi.default_params()
     kappa = np.float32(8e5) * (1 + 0.05 * np.sin(np.arange(n_members)))  # stays above 7.27e5: no 1 800-sweep polar rows
     field, k0, k1 = engine.substep_launch_order(p, 384, 192, n_members, kappa.astype(np.float32))
@@ -60,6 +61,13 @@ def test_substep_order_is_a_partition_and_dearest_first(n_members):
         assert 0 <= a < b <= 192
         cover[f, a:b] += 1
     assert (cover == 1).all()
-    head = [(a, b) for a, b in zip(k0[: 4 * n_members], k1[: 4 * n_members])]
-    assert all(a <= 1 < b or a <= 190 < b for a, b in head)  # rows 1 and 190: the 232-sweep rows of the default grid
+    n = len(field)
+    assert n <= 2048
+    long_chain = np.array([(a <= 1 < b) or (a <= 190 < b) for a, b in zip(k0, k1)])  # rows 1 and 190: 232 sweeps
+    assert long_chain.sum() == 4 * n_members
+    if n <= 1024:
+        assert long_chain[: 4 * n_members].all()
+    else:
+        assert n > 1900  # the slots are used
+        assert not (long_chain[: n - 1024] & long_chain[1024:]).any()
     assert len(engine.substep_launch_order(p, 96, 48, 2)[0]) == 0  # other grids keep the band kernels
