@@ -50,6 +50,15 @@ __device__ __forceinline__ void wait_all_but(int younger) {
   }
 }
 
+// ... where `younger` is the same number row after row in the middle of a strip: one compare instead of the switch's
+// tree of six (a wavefront pays ~100 cycles for that tree, three times per row)
+template <int STEADY>
+__device__ __forceinline__ void wait_all_but_mostly(int younger) {
+  static_assert(STEADY >= 0 && STEADY < 31, "the switch's range");
+  if (__builtin_expect(younger == STEADY, 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
+  else wait_all_but(younger);
+}
+
 // LDS byte addresses of a lane, relative to the start of a slot / of the output row
 struct LaneAddr {
   unsigned a;     // first row of a pair: 24 * lane

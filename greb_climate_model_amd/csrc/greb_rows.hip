@@ -81,7 +81,8 @@ __device__ __forceinline__ void issue_row(Walk& c, int x, int slot) {
 // the row in `slot` has landed: all but the `younger` operations issued after its LDS-DMA may still be in flight
 __device__ __forceinline__ void wait_row(const Walk& c, int slot) {
   const int younger = c.ops - (int)((((slot >> 2) ? c.gend2 : c.gend) >> (16 * (slot & 3))) & 0xffff);
-  wait_all_but(younger);
+  // mid-strip: the row was requested kRowsSlots steps ago, a step issues three LDS-DMA operations and two stores
+  wait_all_but_mostly<2 + 5 * (kRowsSlots - 1)>(younger);
 }
 
 __device__ __forceinline__ void read_row(const Walk& c, int slot, float (&T)[6], float (&w)[6]) {

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
     PairRaw raw;
     if (have) {
       const int slot = row & (kRing - 1);
-      wait_all_but(ops - (int)((gT >> (16 * slot)) & 0xffff));
+      // (mid-strip the row was requested four steps ago: 2 + 3 x 8 + 3 operations since)
+      wait_all_but_mostly<29>(ops - (int)((gT >> (16 * slot)) & 0xffff));
       read_pair_issue(L, lb + kRingBase + slot * kSlotB, raw); // ... and the window shifts under the LDS latency
     }
 #pragma unroll
@@ -255,8 +256,8 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
     ops += 2;
     GREB_STEP_STAMP(5);
     GREB_STEP_PHASE(3);
-    if (r + 1 < k1) { // the next row's winds
-      wait_all_but(ops - (int)((gU >> (16 * ((r + 1) & 1))) & 0xffff));
+    if (r + 1 < k1) { // the next row's winds (requested at the start of the previous step: 13 operations since, mid-strip)
+      wait_all_but_mostly<13>(ops - (int)((gU >> (16 * ((r + 1) & 1))) & 0xffff));
       read_pair(L, lb + kWindBase + ((r + 1) & 1) * kSlotB, u, v);
     }
     GREB_STEP_PHASE(4);
