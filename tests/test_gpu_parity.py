@@ -351,6 +351,37 @@ def test_chain_clamp_g384(eng_mod, oracle_lib, inputs384):
     assert n_clamped > 0  # the cases do drive points to the clamp
 
 
+def test_chain_loop_flavours_g384(eng_mod, oracle_lib, inputs384):
+    """The three FAST loops of a 384-point diffusion chain (greb_chain6.h) against the oracle's sweeps WITH their clamp:
+    rows whose values lie within a factor 64 (and whose weights make the sweep a convex combination) run without any
+    clamp test -- the proof is in chain_stays_positive, this is its experiment: the harshest admissible input, 1 and 60
+    alternating along the 225- / 82-sweep rows --; a wider positive range carries the minimum along; zeros take the
+    stop-before loop.  Every flavour within the FAST tolerance of the sequentially clamped reference result."""
+    from greb_climate_model_amd import abi, workload
+    p = abi.default_params()
+    Ta, q, ityr = workload.routine_inputs_g384(inputs384)
+    o = oracle_lib.Oracle(inputs384, p)
+    wa = o.field(5).copy()
+    f = np.float32
+    rng = np.random.default_rng(64)
+    polar = [0, 1, 2, 3, 4, 187, 188, 189, 190, 191]
+    narrow = Ta.copy(); narrow[polar] = (1 + 59 * (np.arange(384) % 2)).astype(f)                 # 1, 60, 1, 60, ...
+    narrow[2] = (1 + 49 * rng.random(384)).astype(f)
+    wide = Ta.copy(); wide[polar] = (10.0 ** rng.uniform(-3, 1, (len(polar), 384))).astype(f)     # four decades, all > 0
+    zeros = narrow.copy(); zeros[1, 5] = f(0); zeros[190, 77] = f(0)
+    for name, X in (("narrow", narrow), ("wide", wide), ("zeros", zeros)):
+        ref = o.diffusion(X, wa)
+        got = eng_mod.diffusion(X[None], wa[None], p)[0]
+        err = np.abs(got.astype(np.float64) - ref)[polar]  # at the scale of the polar rows themselves
+        tol = 4 * float(np.spacing(np.abs(X[polar]).max()))  # 225 sweeps later: 4 ulp of the rows' largest value (measured 1-2)
+        print(f"chain flavour {name}: polar rows max |FAST - oracle| = {err.max():.3e} (tolerance {tol:.3e})")
+        assert err.max() <= tol, (name, err.max(), tol)
+        if name == "narrow":  # (a total decay of 89 % would be the trace of a clamp here: the rows relax to their mean, ~30)
+            assert not np.any((X[polar] > 0) & (ref[polar] / np.maximum(wa[polar], f(1e-30)) <= -0.89 * X[polar]))
+        assert np.array_equal(eng_mod.diffusion(X[None], wa[None], p, strict=True)[0], ref)
+    o.close()
+
+
 def test_row_strip_substep_equals_band_kernel_strict(eng_mod, inputs384):
     """The row-strip circulation sub-step (greb_step_rows.hip; GREB_F_ROW_STRIPS) in STRICT arithmetic against the band
     kernel in STRICT arithmetic: the same expression trees through completely different data movement (wavefront-private

@@ -34,6 +34,11 @@ DEALS = {  # a leading "P<w>:" puts the polar chains on wave w (default 6); the 
     "n5":    "P6:S0+F0 S1+F1 F3+F4+H S2+F2 T0 T1 T2",
     "n6":    "P6:S0 S1 H+F3+F4 S2 T0+F0 T1+F1 T2+F2",
     "n7":    "P6:F0+S0 F1+S1 H+F3+F4 F2+S2 T0 T1 T2",
+    # after the chain wave got lighter (no test between its sweeps: 4 437 -> 4 132 busy cycles): work towards SIMD 2
+    "r1":    "P6:S0+F0 S2+F1 T1+F3+F2 T2+H S1 T0 F4",
+    "r2":    "P6:S0 S2+F1 T1+F3+F0 T2+H+F2 S1 T0 F4",
+    "r3":    "P6:S0+F0 S2 T1+F3+F1 T2+H+F2 S1 T0 F4",
+    "r4":    "P6:S0 S2+F1 T1+F3 T2+H+F2 S1 T0 F0+F4",
 }
 
 
