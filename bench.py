@@ -440,8 +440,8 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
 
     r, dt, ok = year_rate(1, None)
     out["config3_single_member"] = {"years_per_s": round(r, 3), "us_per_substep_launch": round(dt / (730 * 25) * 1e6, 2),
-                                    "finite": ok, "bound": "latency of one wavefront's 232-sweep polar row per launch: 22.0 of the ~23.5 us "
-                                                           "(profiles/r03_g384_substep_stamps.txt: 210 cycles per dependent sweep)"}
+                                    "finite": ok, "bound": "latency of one wavefront's 232-sweep polar row per launch: 14.9 of the ~18.5 us "
+                                                           "(profiles/r03_g384_substep_stamps.txt: 138-147 cycles per dependent sweep, one instruction per 4.0 cycles)"}
     ov = ensemble.perturbed_physics(64, p)
     as_dicts = lambda rows: [dict(zip(ensemble.PERTURBED, map(float, row))) for row in rows]
     slow = ov[:, 3] < 7.27e5
@@ -468,8 +468,9 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
     keep = ov[~slow]
     r, dt, ok = year_rate(len(keep), as_dicts(keep))
     out["config5_without_those_members"] = {"members": int(len(keep)), "member_years_per_s": round(r, 2), "finite": ok,
-                                            "bound": "row-strip sub-step (greb_step_rows.hip): two wavefronts per SIMD at 187 VGPRs, ~3 900 cycles per streamed row and wavefront "
-                                                     "(tools/stamp_step_rows.py); the launch cannot be shorter than its 232-sweep polar rows (22 us)"}
+                                            "bound": "instruction issue of the row-strip sub-step (greb_step_rows.hip): one instruction per SIMD every 4 cycles, 14 M vector "
+                                                     "instructions per launch = 22.7 us on 1 024 SIMDs perfectly balanced; two wavefronts per SIMD at 187 VGPRs, "
+                                                     "one round of <= 2 048 strips (tools/step_timeline.py: kernel 33-34 us, the rest is the point-physics launch and launch gaps)"}
     # standalone diffusion sweep, HIP events on the launching stream
     batch = 1024
     n = batch * nx * ny
