@@ -130,6 +130,7 @@ struct greb_engine {
   bool step_rows = false;                                   // 384-wide grid: the row-strip sub-step (greb_step_rows.hip)
   bool step_rows_always = false;                            // GREB_F_ROW_STRIPS
   std::map<int, std::pair<RowsTask*, int>> step_tasks;      // its launch order, per number of members run
+  int cus = 0;                                              // compute units of the device (4 SIMDs each)
   std::vector<Phys> h_phys;
   // model clock
   long long it_flux = 0; // steps done in the flux phase
@@ -200,9 +201,8 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     auto it = e->step_tasks.find(nrun);
     if (it == e->step_tasks.end()) {
       RowsTask* dev = nullptr; int n = 0;
-      int cus = 0;
-      HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-      HIP_TRY(e, step_rows_make_tasks(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, cus * kStepRowsSlotsPerCu, &dev, &n));
+      if (e->cus <= 0) HIP_TRY(e, hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, e->device));
+      HIP_TRY(e, step_rows_make_tasks(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, e->cus * kStepRowsSlotsPerCu, &dev, &n));
       it = e->step_tasks.emplace(nrun, std::make_pair(dev, n)).first;
     }
     step_tasks = it->second.first; n_step_tasks = it->second.second;
@@ -217,7 +217,7 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     for (int tt = 0; tt < a.nsub; ++tt) {
       if (rows)
         HIP_TRY(e, launch_substep_rows(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, step_tasks,
-                                       n_step_tasks, 2 * nrun, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
+                                       n_step_tasks, e->cus * 4, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
       else
         HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
                                         e->ny, nrun, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));

@@ -106,7 +106,7 @@ hipError_t step_rows_make_tasks(const RowTables* tabs_host, const int* tab_index
                                 int n_slots, RowsTask** dev, int* n);
 hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
                                const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, int n_tasks,
-                               int n_fields, int ny, bool strict, hipStream_t s, bool calm_vapor);
+                               int n_simd, int ny, bool strict, hipStream_t s, bool calm_vapor);
 hipError_t launch_advection(const float* T1, const float* wz, const float* u, const float* v, float* dX,
                             const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s);
 // 24 sub-steps; 96x48 uses the fused LDS loop of the engine, other grids launch per sub-step

@@ -419,16 +419,14 @@ extern "C" int greb_tuning_step_stamps(unsigned long long* out6) {
 
 hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
                                const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, int n_tasks,
-                               int n_fields, int ny, bool strict, hipStream_t s, bool calm_vapor) {
+                               int n_simd, int ny, bool strict, hipStream_t s, bool calm_vapor) {
   // A chain never waits, so at equal priority (it is the older wavefront) it takes every issue slot of its SIMD and the
   // streaming strip beside it -- which needs few slots but a long time, it waits for memory -- stands still until the
   // chain is over.  Where SIMDs are shared (more tasks than SIMDs) the streaming rows therefore issue first and the
   // chains fill what is left: the pair ends after max(wall, sum of issues) instead of their sum.  With a SIMD per task
   // (few fields) the long chains keep their raised priority.
-  static const int chain_fields = tuning_int("GREB_STEP_PRIO_FIELDS", -1); // -DGREB_TUNING builds only
-  int cus = 0, dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  const bool chains_first = chain_fields >= 0 ? n_fields <= chain_fields : n_tasks <= cus * 4;
+  static const int forced = tuning_int("GREB_STEP_CHAINS_FIRST", -1); // -DGREB_TUNING builds only (A/B)
+  const bool chains_first = forced >= 0 ? forced != 0 : n_tasks <= n_simd;
   StepArgs a{X, W2, u, v, Xnew, tabs_dev, tab_index_dev, tasks, ny, calm_vapor ? 1 : 0, chains_first ? 1 : 0, nullptr, nullptr};
 #ifdef GREB_TUNING
   a.stamps = g_step_stamps;
