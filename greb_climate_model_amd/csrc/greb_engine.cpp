@@ -129,7 +129,8 @@ struct greb_engine {
   std::vector<int> h_tab_index;
   bool step_rows = false;                                   // 384-wide grid: the row-strip sub-step (greb_step_rows.hip)
   bool step_rows_always = false;                            // GREB_F_ROW_STRIPS
-  std::map<int, std::pair<RowsTask*, int>> step_tasks;      // its launch order, per number of members run
+  struct StepOrder { RowsTask* dev; int n; RowsTask head[kStepHeadTasks]; };
+  std::map<int, StepOrder> step_tasks;                      // its launch order, per number of members run
   int cus = 0;                                              // compute units of the device (4 SIMDs each)
   std::vector<Phys> h_phys;
   // model clock
@@ -195,17 +196,19 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
   // STRICT keeps the band kernel (1 member 64.7 against 74.6 us: its two chains per row run one after the other in
   // one wave here); GREB_F_ROW_STRIPS takes the strips there too.
   const bool rows = e->step_rows && (e->step_rows_always || !e->strict);
-  const RowsTask* step_tasks = nullptr;
+  const RowsTask *step_tasks = nullptr, *step_head = nullptr;
   int n_step_tasks = 0;
   if (rows) {
     auto it = e->step_tasks.find(nrun);
     if (it == e->step_tasks.end()) {
       RowsTask* dev = nullptr; int n = 0;
       if (e->cus <= 0) HIP_TRY(e, hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, e->device));
-      HIP_TRY(e, step_rows_make_tasks(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, e->cus * kStepRowsSlotsPerCu, &dev, &n));
-      it = e->step_tasks.emplace(nrun, std::make_pair(dev, n)).first;
+      greb_engine::StepOrder so{};
+      HIP_TRY(e, step_rows_make_tasks(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, e->cus * kStepRowsSlotsPerCu, &dev, &n, so.head));
+      so.dev = dev; so.n = n;
+      it = e->step_tasks.emplace(nrun, so).first;
     }
-    step_tasks = it->second.first; n_step_tasks = it->second.second;
+    step_tasks = it->second.dev; n_step_tasks = it->second.n; step_head = it->second.head;
   }
   HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
   static const int steps = tuning_int("GREB_DEBUG_NSTEPS", kNT); // -DGREB_TUNING builds only: a short stretch for counter passes
@@ -217,7 +220,7 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     for (int tt = 0; tt < a.nsub; ++tt) {
       if (rows)
         HIP_TRY(e, launch_substep_rows(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, step_tasks,
-                                       n_step_tasks, e->cus * 4, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
+                                       step_head, n_step_tasks, e->cus * 4, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
       else
         HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
                                         e->ny, nrun, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
@@ -394,7 +397,8 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
     HIP_TRY(e, hipMemcpy(e->W2, wz_air.data(), np * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->W2 + np, wz_vapor.data(), np * sizeof(float), hipMemcpyHostToDevice));
     static const bool no_step_rows = tuning_int("GREB_NO_STEP_ROWS", 0) != 0; // -DGREB_TUNING builds only (A/B)
-    e->step_rows = !no_step_rows && step_rows_supported(e->h_tabs.data(), (int)e->h_tabs.size(), nx, ny);
+    e->step_rows = !no_step_rows && n_members < (1 << (kStepFieldBits - 1)) && // (field and table index share a task word)
+                   step_rows_supported(e->h_tabs.data(), (int)e->h_tabs.size(), nx, ny);
     e->step_rows_always = (flags & GREB_F_ROW_STRIPS) != 0;
   }
   return 0;
@@ -408,7 +412,7 @@ int greb_engine_destroy(greb_engine* e) {
                   e->corr, e->corr_index, e->tab_index, e->tabs, e->phys, e->co2_dev, e->monthly_dev, e->yearly_dev,
                   e->Xa, e->Xb, e->red, e->W2};
   for (void* q : ptrs) if (q) (void)hipFree(q);
-  for (auto& kv : e->step_tasks) if (kv.second.first) (void)hipFree(kv.second.first);
+  for (auto& kv : e->step_tasks) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (int i = 0; i < 2; ++i) {
     if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
     if (e->ev_free[i]) (void)hipEventDestroy(e->ev_free[i]);
@@ -695,11 +699,11 @@ int greb_substep_launch_order(const greb_params* p, int nx, int ny, int n_member
   std::vector<RowTables> tabs((size_t)n_members);
   std::vector<int> idx((size_t)n_members);
   for (int m = 0; m < n_members; ++m) { compute_row_tables(*p, kappa ? kappa[m] : p->kappa, nx, ny, tabs[m]); idx[m] = m; }
-  if (!step_rows_supported(tabs.data(), n_members, nx, ny)) return 0;
+  if (n_members >= (1 << (kStepFieldBits - 1)) || !step_rows_supported(tabs.data(), n_members, nx, ny)) return 0;
   std::vector<RowsTask> tasks;
   step_rows_tasks(tabs.data(), idx.data(), n_members, ny, 256 * kStepRowsSlotsPerCu, tasks); // an MI355X: 256 CUs
   for (size_t i = 0; i < tasks.size() && (int)i < capacity; ++i) {
-    field[i] = tasks[i].field; k0[i] = tasks[i].rows & 0xff; k1[i] = (tasks[i].rows >> 8) & 0x1ff;
+    field[i] = tasks[i].field & ((1 << kStepFieldBits) - 1); k0[i] = tasks[i].rows & 0xff; k1[i] = (tasks[i].rows >> 8) & 0x1ff;
   }
   return (int)tasks.size();
 }

@@ -102,11 +102,13 @@ bool step_rows_supported(const RowTables* tabs, int n_tabs, int nx, int ny);
 constexpr int kStepRowsSlotsPerCu = 8; // wavefronts of the sub-step kernel a CU holds (187 VGPRs, 19.5 KB of LDS each)
 void step_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members, int ny, int n_slots,
                      std::vector<RowsTask>& tasks);
+constexpr int kStepFieldBits = 16;  // a sub-step task's field word: field | row-table index << 16 (at most 32 767 members)
+constexpr int kStepHeadTasks = 16; // the first tasks of the launch order travel in the kernel arguments (see StepArgs)
 hipError_t step_rows_make_tasks(const RowTables* tabs_host, const int* tab_index_host, int n_members, int ny,
-                                int n_slots, RowsTask** dev, int* n);
+                                int n_slots, RowsTask** dev, int* n, RowsTask* head /* [kStepHeadTasks] */);
 hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
-                               const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, int n_tasks,
-                               int n_simd, int ny, bool strict, hipStream_t s, bool calm_vapor);
+                               const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, const RowsTask* head_host,
+                               int n_tasks, int n_simd, int ny, bool strict, hipStream_t s, bool calm_vapor);
 hipError_t launch_advection(const float* T1, const float* wz, const float* u, const float* v, float* dX,
                             const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s);
 // 24 sub-steps; 96x48 uses the fused LDS loop of the engine, other grids launch per sub-step

@@ -18,6 +18,7 @@
 //   * tasks are launched dearest first: the long chains start in the first microsecond.
 // STRICT keeps the reference's expression trees (bit-exact), FAST the re-associated ones of the other kernels.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "greb_rows.h"
@@ -38,7 +39,11 @@ struct StepArgs {
   float* Xnew;
   const RowTables* tabs;
   const int* tab_index;    // [n_members]
-  const RowsTask* tasks;   // field = 2 * member + tracer
+  const RowsTask* tasks;   // field word = (2 * member + tracer) | the member's row-table index << 16 (kStepFieldBits)
+  // The first tasks of the launch -- with few fields the 232-sweep polar rows, which ARE the launch -- by value: a
+  // wavefront's start is a chain of dependent memory latencies (arguments -> task -> rows, ~0.4 us each after the
+  // cache invalidation at the kernel boundary), and these tasks skip the middle one
+  unsigned long long head[kStepHeadTasks];
   int ny, calm_odd;        // calm_odd: the vapour fields see zero wind (greb.original.model.f90:560-564)
   int chains_first;        // who issues first where a chain and a streaming strip share a SIMD (launch_substep_rows)
   unsigned long long* stamps; // -DGREB_TUNING builds only (null otherwise): s_memtime stamps of task 0
@@ -63,21 +68,25 @@ template <bool STRICT>
 __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
   extern __shared__ __align__(16) float lds_raw[];
   lfloat* lds = (lfloat*)lds_raw;
-  const RowsTask task = a.tasks[blockIdx.x];
-  const int fld = task.field;
-  if (fld < 0) return;
-#ifdef GREB_TUNING
-  if (a.timeline && threadIdx.x == 0) {
-    a.timeline[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); // wave, SIMD, CU, SE ids
-    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    a.timeline[2 * gridDim.x + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+  // (field, rows) as ONE 8-byte scalar load issued with the argument loads: as two fields with a test between them the
+  // compiler loaded them one after the other, a memory latency each
+  // (each arm ends in its own readfirstlane: as a plain conditional the compiler selects between the two ADDRESSES and
+  // issues one flat vector load -- the task, and every loop bound derived from it, in VGPRs; an opaque asm statement
+  // instead makes every later scalar load of the kernel a vector load, tab_index first)
+  int fld, task_rows; // fld: the field in the low 16 bits, the row-table index above
+  if (blockIdx.x < kStepHeadTasks) {
+    const unsigned long long t = a.head[blockIdx.x];
+    fld = __builtin_amdgcn_readfirstlane((int)(unsigned)t); task_rows = __builtin_amdgcn_readfirstlane((int)(t >> 32));
+  } else {
+    const unsigned long long t = *reinterpret_cast<const unsigned long long*>(a.tasks + blockIdx.x);
+    fld = __builtin_amdgcn_readfirstlane((int)(unsigned)t); task_rows = __builtin_amdgcn_readfirstlane((int)(t >> 32));
   }
-#endif
-  const int k0 = task.rows & 0xff, k1 = (task.rows >> 8) & 0x1ff, ny = a.ny;
+  const int tab_idx = (int)((unsigned)fld >> kStepFieldBits);
+  fld &= (1 << kStepFieldBits) - 1;
+  const int k0 = task_rows & 0xff, k1 = (task_rows >> 8) & 0x1ff, ny = a.ny;
   const unsigned lane = threadIdx.x;
   const int member = fld >> 1, tracer = fld & 1;
-  const RowTables& tab = a.tabs[a.tab_index[member]];
+  const RowTables& tab = a.tabs[tab_idx]; // (in the task word: one dependent memory latency less before the first row)
   const size_t np = (size_t)kNx * ny;
   const float* Xf = a.X + (size_t)fld * np;
   const float* wf = a.W2 + (size_t)tracer * np;
@@ -368,14 +377,15 @@ void step_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members,
   }
   tasks.clear();
   tasks.reserve(all.size());
-  for (const T& x : all) tasks.push_back({x.field, x.k0 | (x.k1 << 8) | kRowsUp});
+  for (const T& x : all) tasks.push_back({x.field | (tab_index[x.field >> 1] << kStepFieldBits), x.k0 | (x.k1 << 8) | kRowsUp});
 }
 
 // the launch order on the device (owned by the caller: the engine keeps one per member count and frees it with itself)
 hipError_t step_rows_make_tasks(const RowTables* tabs_host, const int* tab_index_host, int n_members, int ny,
-                                int n_slots, RowsTask** dev, int* n) {
+                                int n_slots, RowsTask** dev, int* n, RowsTask* head) {
   std::vector<RowsTask> host;
   step_rows_tasks(tabs_host, tab_index_host, n_members, ny, n_slots, host);
+  for (int i = 0; i < kStepHeadTasks; ++i) head[i] = i < (int)host.size() ? host[(size_t)i] : RowsTask{0, 0};
   hipError_t e = hipMalloc(dev, host.size() * sizeof(RowsTask));
   if (e != hipSuccess) return e;
   if ((e = hipMemcpy(*dev, host.data(), host.size() * sizeof(RowsTask), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -418,8 +428,8 @@ extern "C" int greb_tuning_step_stamps(unsigned long long* out6) {
 #endif
 
 hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
-                               const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, int n_tasks,
-                               int n_simd, int ny, bool strict, hipStream_t s, bool calm_vapor) {
+                               const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, const RowsTask* head_host,
+                               int n_tasks, int n_simd, int ny, bool strict, hipStream_t s, bool calm_vapor) {
   // A chain never waits, so at equal priority (it is the older wavefront) it takes every issue slot of its SIMD and the
   // streaming strip beside it -- which needs few slots but a long time, it waits for memory -- stands still until the
   // chain is over.  Where SIMDs are shared (more tasks than SIMDs) the streaming rows therefore issue first and the
@@ -427,7 +437,9 @@ hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, 
   // (few fields) the long chains keep their raised priority.
   static const int forced = tuning_int("GREB_STEP_CHAINS_FIRST", -1); // -DGREB_TUNING builds only (A/B)
   const bool chains_first = forced >= 0 ? forced != 0 : n_tasks <= n_simd;
-  StepArgs a{X, W2, u, v, Xnew, tabs_dev, tab_index_dev, tasks, ny, calm_vapor ? 1 : 0, chains_first ? 1 : 0, nullptr, nullptr};
+  StepArgs a{X, W2, u, v, Xnew, tabs_dev, tab_index_dev, tasks, {}, ny, calm_vapor ? 1 : 0, chains_first ? 1 : 0, nullptr, nullptr};
+  static_assert(sizeof(RowsTask) == sizeof(unsigned long long), "a task is one 8-byte load: field in the low half");
+  std::memcpy(a.head, head_host, sizeof(a.head));
 #ifdef GREB_TUNING
   a.stamps = g_step_stamps;
   a.timeline = n_tasks <= g_step_timeline_cap ? g_step_timeline : nullptr;
