@@ -81,6 +81,14 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
     const unsigned long long t = *reinterpret_cast<const unsigned long long*>(a.tasks + blockIdx.x);
     fld = __builtin_amdgcn_readfirstlane((int)(unsigned)t); task_rows = __builtin_amdgcn_readfirstlane((int)(t >> 32));
   }
+#ifdef GREB_TUNING
+  if (a.timeline && threadIdx.x == 0) {
+    a.timeline[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); // wave, SIMD, CU, SE ids
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.timeline[2 * gridDim.x + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   const int tab_idx = (int)((unsigned)fld >> kStepFieldBits);
   fld &= (1 << kStepFieldBits) - 1;
   const int k0 = task_rows & 0xff, k1 = (task_rows >> 8) & 0x1ff, ny = a.ny;

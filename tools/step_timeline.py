@@ -26,6 +26,8 @@ e.run(1, 680.0, monthly_dev_ptr=buf.data_ptr()); torch.cuda.synchronize()
 out = (C.c_ulonglong * (3 * n))()
 assert L.greb_tuning_step_timeline(out, n) == 0
 a = np.array(out[:2 * n], np.int64).reshape(n, 2)
+if (a == 0).any() or (a[:, 1] < a[:, 0]).any() or a.max() - a.min() > 100 * 1000 * 1000:  # (a launch is not a second long)
+    sys.exit(f"incomplete stamps: {int((a == 0).sum())} zero entries of {a.size} -- is the tuning library current?")
 hw = np.array(out[2 * n:], np.uint64)
 t0 = a[:, 0].min()
 st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0  # us
