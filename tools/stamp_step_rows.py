@@ -18,9 +18,10 @@ st = (C.c_ulonglong * 16)()
 assert L.greb_tuning_step_stamps(st) == 0
 s = list(st)
 names = ["own row + wind landed (from loop entry)", "flux / window set-up", "diffusion chain (225 sweeps)", "advection chain (7 sweeps)", "meridional part + store"]
-for n, a, b in zip(names, s[:6], s[1:6]):
-    print(f"{n:45s} {b - a:8d} cycles")
-print(f"{'loop entry -> row stored':45s} {s[5] - s[0]:8d} cycles = {(s[5] - s[0]) / 2.4e3:.2f} us at 2.4 GHz")
+if M == 1:  # task 0 is the 232-sweep polar row only while every task has a SIMD to itself (step_rows_tasks)
+    for n, a, b in zip(names, s[:6], s[1:6]):
+        print(f"{n:45s} {b - a:8d} cycles")
+    print(f"{'loop entry -> row stored':45s} {s[5] - s[0]:8d} cycles = {(s[5] - s[0]) / 2.4e3:.2f} us at 2.4 GHz")
 if s[10]:
     print(f"last task of the launch (a streaming strip of {s[10]} rows), {M} member(s): window fill {s[11] - s[8]} cycles, "
           f"then {(s[9] - s[11]) / s[10]:.0f} cycles per row; whole task {(s[9] - s[8]) / 2.4e3:.2f} us at 2.4 GHz")
