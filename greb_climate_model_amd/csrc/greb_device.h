@@ -367,8 +367,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (HIP's __fdividef is a plain IEEE division unless the whole file is built with fast-math: ~10 instructions.  The
 // FAST policy wants ONE v_rcp_f32 + one multiply; 19 divisions per point made up 44 % of the point-physics phase.)
 template <bool EXACT> __device__ __forceinline__ float fdiv(float a, float b) { return EXACT ? a / b : a * __builtin_amdgcn_rcpf(b); }
-// ... and by a constant of the run whose reciprocal the host has rounded once (Phys::inv_*)
-template <bool EXACT> __device__ __forceinline__ float fdivc(float a, float b, float inv_b) { return EXACT ? a / b : a * inv_b; }
 // (HIP's __logf / __expf are not bare hardware instructions either -- OCML adds denormal scaling and an
 // extended-precision ln2 / log2e product, ~11 instructions per call, 16 calls per quad.  Replacing them by
 // v_log_f32 * ln2 and v_exp_f32(x * log2e) keeps parity (Tsurf 1.42e-5 K RMS) but measured SLOWER, A/B in one gpurun
@@ -388,12 +386,6 @@ struct Phys { // namelist physics_par + derived capacities, broadcast to the ker
   float p_emi[10];
   float cap_ocean, cap_land, cap_air;
   float dt; // float(dt)
-  // reciprocals of the divisors that are constants of the run, for the FAST policy (fdivc): the point-physics phase is
-  // bound by instruction issue, and a v_rcp_f32 is a quarter-rate instruction -- 13.5 of them per point became 4
-  float inv_dTl, inv_dTo;   // 1 / (Tl_ice2 - Tl_ice1), 1 / (To_ice2 - To_ice1)
-  float inv_pemi8;          // 1 / p_emi[8]
-  float inv_latent_vapor;   // 1 / (cq_latent * r_qviwv)
-  float inv_cap_air, inv_cap_ocean, inv_dt;
 };
 
 __device__ __forceinline__ float pow4_ref(float x) {
@@ -408,14 +400,7 @@ __device__ __forceinline__ void sw_radiation(const Phys& P, float Ts, float z_to
 #pragma clang fp contract(off)
   const float a_atmos = cld * P.a_cloud;
   float a_surf = 0.f;
-  if constexpr (!EXACT) {
-    // the ramp as ONE clamped expression (x <= 0 and x >= 1 give the reference's end values exactly): 7 instructions
-    // where the six tests of the reference's form compile to compares and selects for both surface kinds
-    const bool land = z_topo >= 0.f;
-    const float T1 = land ? P.Tl_ice1 : P.To_ice1, inv = land ? P.inv_dTl : P.inv_dTo;
-    const float x = __builtin_amdgcn_fmed3f((Ts - T1) * inv, 0.f, 1.f);
-    a_surf = P.a_no_ice + P.da_ice * (1.f - x);
-  } else if (z_topo >= 0.f) {
+  if (z_topo >= 0.f) {
     if (Ts <= P.Tl_ice1) a_surf = P.a_no_ice + P.da_ice;
     if (Ts >= P.Tl_ice2) a_surf = P.a_no_ice;
     if (Ts > P.Tl_ice1 && Ts < P.Tl_ice2)
@@ -444,7 +429,7 @@ __device__ __forceinline__ void lw_radiation(const Phys& P, float Ts, float Ta, 
   float e = P.p_emi[3] * flog<EXACT>(P.p_emi[0] * e_co2 + P.p_emi[1] * e_vapor + P.p_emi[2]) + P.p_emi[6]
             + P.p_emi[4] * flog<EXACT>(P.p_emi[0] * e_co2 + P.p_emi[2])
             + P.p_emi[5] * flog<EXACT>(P.p_emi[1] * e_vapor + P.p_emi[2]);
-  e = fdivc<EXACT>(P.p_emi[7] - cld, P.p_emi[8], P.inv_pemi8) * (e - P.p_emi[9]) + P.p_emi[9];
+  e = fdiv<EXACT>(P.p_emi[7] - cld, P.p_emi[8]) * (e - P.p_emi[9]) + P.p_emi[9];
   if (xsw & kXLwLinear) e = e + 0.022f / (0.15f * 24.f) * P.r_qviwv * (q - qclim); // greb.original.model.f90:430
   em = e;
   LWsurf = -P.sig * pow4_ref(Ts);
@@ -465,7 +450,7 @@ __device__ __forceinline__ void hydro(const Phys& P, float Ts, float q, float u,
   float qs = 3.75e-3f * fexp<EXACT>(fdiv<EXACT>(17.08085f * (Ts - 273.15f), Ts - 273.15f + 234.175f));
   qs = qs * ez;
   Qlat = (q - qs) * abswind * P.cq_latent * P.rho_air * P.ce * swet;
-  dq_eva = EXACT ? fdiv<EXACT>(fdiv<EXACT>(-Qlat, P.cq_latent), P.r_qviwv) : -Qlat * P.inv_latent_vapor;
+  dq_eva = fdiv<EXACT>(fdiv<EXACT>(-Qlat, P.cq_latent), P.r_qviwv);
   dq_rain = P.cq_rain * q;
   Qlat_air = -dq_rain * P.cq_latent * P.r_qviwv;
 }
@@ -479,22 +464,12 @@ __device__ __forceinline__ void deep_ocean(const Phys& P, float Ts, float To, fl
   if (xsw & kXNoDeepOcean) { dT_ocean = dTo = 0.f; return; } // greb.original.model.f90:513-515
   float a = 0.f, b = 0.f;
   const float dmld = mld - mld_prev;
-  if constexpr (!EXACT) { // the two layer depths' reciprocals once each (four divisions in the reference's form)
-    const float r_deep = __builtin_amdgcn_rcpf(z_ocean - mld), r_mix = __builtin_amdgcn_rcpf(mld);
-    const bool open = z_topo < 0.f && Ts >= P.To_ice2;
-    if (open && dmld < 0.f) a = -dmld * r_deep * (Ts - To);
-    if (open && dmld > 0.f) b = dmld * r_mix * (To - Ts);
-    const float Tx = fmaxf(P.To_ice2, Ts), k = P.dt * P.co_turb * P.inv_cap_ocean;
-    a = 0.5f * a + k * (Tx - To) * r_deep;
-    b = 0.5f * b + k * (To - Tx) * r_mix;
-  } else {
-    if (z_topo < 0.f && Ts >= P.To_ice2 && dmld < 0.f) a = fdiv<EXACT>(-dmld, z_ocean - mld) * (Ts - To);
-    if (z_topo < 0.f && Ts >= P.To_ice2 && dmld > 0.f) b = fdiv<EXACT>(dmld, mld) * (To - Ts);
-    a = 0.5f * a; b = 0.5f * b;
-    const float Tx = P.To_ice2 > Ts ? P.To_ice2 : Ts;
-    a = a + fdiv<EXACT>(P.dt * P.co_turb * (Tx - To), P.cap_ocean * (z_ocean - mld));
-    b = b + fdiv<EXACT>(P.dt * P.co_turb * (To - Tx), P.cap_ocean * mld);
-  }
+  if (z_topo < 0.f && Ts >= P.To_ice2 && dmld < 0.f) a = fdiv<EXACT>(-dmld, z_ocean - mld) * (Ts - To);
+  if (z_topo < 0.f && Ts >= P.To_ice2 && dmld > 0.f) b = fdiv<EXACT>(dmld, mld) * (To - Ts);
+  a = 0.5f * a; b = 0.5f * b;
+  const float Tx = P.To_ice2 > Ts ? P.To_ice2 : Ts;
+  a = a + fdiv<EXACT>(P.dt * P.co_turb * (Tx - To), P.cap_ocean * (z_ocean - mld));
+  b = b + fdiv<EXACT>(P.dt * P.co_turb * (To - Tx), P.cap_ocean * mld);
   dTo = a; dT_ocean = b;
 }
 
@@ -503,12 +478,7 @@ template <bool EXACT = true>
 __device__ __forceinline__ float seaice(const Phys& P, float Ts, float z_topo, float glacier, float mld,
                                         float cap_surf, unsigned xsw = 0) {
 #pragma clang fp contract(off)
-  if constexpr (!EXACT) {
-    if (z_topo < 0.f) { // the ramp as one clamped expression, as in sw_radiation
-      const float x = __builtin_amdgcn_fmed3f((Ts - P.To_ice1) * P.inv_dTo, 0.f, 1.f), open_cap = P.cap_ocean * mld;
-      cap_surf = x >= 1.f ? open_cap : P.cap_land + (open_cap - P.cap_land) * x;
-    }
-  } else if (z_topo < 0.f) {
+  if (z_topo < 0.f) {
     if (Ts <= P.To_ice1) cap_surf = P.cap_land;
     if (Ts >= P.To_ice2) cap_surf = P.cap_ocean * mld;
     if (Ts > P.To_ice1 && Ts < P.To_ice2)

@@ -92,10 +92,6 @@ Phys make_phys(const greb_params& p, const greb_member_overrides* o) {
   P.cap_land = p.cp_land * p.rho_land * p.d_land;  // :187
   P.cap_air = p.cp_air * p.rho_air * p.d_air;      // :188
   P.dt = (float)p.dt;
-  P.inv_dTl = 1.f / (P.Tl_ice2 - P.Tl_ice1); P.inv_dTo = 1.f / (P.To_ice2 - P.To_ice1);
-  P.inv_pemi8 = 1.f / P.p_emi[8];
-  P.inv_latent_vapor = 1.f / (P.cq_latent * P.r_qviwv);
-  P.inv_cap_air = 1.f / P.cap_air; P.inv_cap_ocean = 1.f / P.cap_ocean; P.inv_dt = 1.f / P.dt;
   return P;
 }
 

@@ -108,12 +108,12 @@ __device__ __forceinline__ PhysOut physics_compute(const MemberArgs& a, const Ph
     if (FLUX) {
       const float dTs = fdiv<STRICT>(P.dt * (sw + LWsurf - LWdown + Qlat + Qsens), cap);                    // :333
       Ts0 = Ts1 + dTs + dT_ocean;                                                              // :334
-      const float dTa = fdivc<STRICT>(P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens), P.cap_air, P.inv_cap_air); // :336
+      const float dTa = fdiv<STRICT>(P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens), P.cap_air);   // :336
       Ta0 = Ta1 + dTa + dTa_crcl;                                                              // :337
       To0 = To1 + dTo;                                                                         // :339
       const float dq = P.dt * (dq_eva + dq_rain);                                              // :341
       q0 = q1 + dq + dq_crcl;                                                                  // :342
-      const float TF = fdivc<STRICT>((tcl - Ts0) * cap, P.dt, P.inv_dt);                                    // :344-345
+      const float TF = fdiv<STRICT>((tcl - Ts0) * cap, P.dt);                                               // :344-345
       Ts0 = Ts1 + dTs + dT_ocean + fdiv<STRICT>(TF * P.dt, cap);                                            // :347
       const float ToF = in.c0.v[e] - To0;                                                      // :349
       To0 = To1 + dTo + ToF;                                                                   // :351
@@ -123,7 +123,7 @@ __device__ __forceinline__ PhysOut physics_compute(const MemberArgs& a, const Ph
     } else {
       const float TF = in.c0.v[e], qF = in.c1.v[e], ToF = in.c2.v[e];
       Ts0 = Ts1 + dT_ocean + fdiv<STRICT>(P.dt * (sw + LWsurf - LWdown + Qlat + Qsens + TF), cap);          // :258
-      Ta0 = Ta1 + dTa_crcl + fdivc<STRICT>(P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens), P.cap_air, P.inv_cap_air); // :260
+      Ta0 = Ta1 + dTa_crcl + fdiv<STRICT>(P.dt * (LWup + LWdown - em * LWsurf + Qlat_air - Qsens), P.cap_air); // :260
       To0 = To1 + dTo + ToF;                                                                   // :262
       float dq = P.dt * (dq_eva + dq_rain) + dq_crcl + qF;                                     // :264
       if (dq <= -q1) dq = -0.9f * q1;                                                          // :265
