@@ -3,11 +3,13 @@
 //
 // One wavefront = one task = a strip of consecutive latitude rows of one (member, tracer) field; no workgroup, no
 // barrier: a wave that owns a 232-sweep polar row (225 diffusion + 7 advection sweeps) starts its chain
-// as soon as ITS row and wind have landed and nobody else waits for it.  That chain is the length of the launch
-// (measured: 210 cycles per sweep -- 36 instructions + the clamp test and the loop -- so 22.0 us for that row with its
-// set-up and epilogue, tools/stamp_step_rows.py); the band kernels (greb_kernels.hip: sweep_kernel<fused>, and round
-// 2's (Tair,q)-pair band kernel) add staging, a workgroup barrier and the band's epilogue to it: 25.1 us per launch for
-// one member, 48 us for 62 -- here 23.2 and 40.8.
+// as soon as ITS row and wind have landed and nobody else waits for it.  With few fields that chain is the length of the
+// launch (138-147 cycles per sweep -- greb_chain6.h: one instruction per 4.0 cycles, no test between the sweeps -- so
+// 14.9 us for that row with its set-up and epilogue, tools/stamp_step_rows.py); the band kernels (greb_kernels.hip:
+// sweep_kernel<fused>, and round 2's (Tair,q)-pair band kernel) add staging, a workgroup barrier and the band's epilogue
+// to it: 25.1 us per launch for one member, 48 us for 62 -- here 18 and 38.5.  With many fields the launch is bound by
+// instruction issue (one vector instruction per SIMD every 4 cycles) and by how evenly the SIMDs are loaded:
+// step_rows_tasks below.
 //   * rows k-2 .. k+2 of the tracer and its weight (the meridional stencils of both operators) are a window in registers
 //     that slides up one row per step; rows arrive by LDS-DMA up to three ahead of it (greb_rows.h: four landing slots,
 //     19.5 KB of LDS per wavefront, eight wavefronts per CU); the zonal halo is a wave rotate (DPP);
@@ -15,7 +17,7 @@
 //   * per row: the zonal edge fluxes once, shared by the diffusion and the advection sweep (greb_device.h: edge-flux
 //     form); rows that iterate run their sweeps in registers (greb_chain6.h), diffusion and advection chains one after
 //     the other in the same wave;
-//   * tasks are launched dearest first: the long chains start in the first microsecond.
+//   * the launch order is ONE round of at most as many tasks as the chip has wavefront slots (step_rows_tasks).
 // STRICT keeps the reference's expression trees (bit-exact), FAST the re-associated ones of the other kernels.
 #include <algorithm>
 #include <cstring>
