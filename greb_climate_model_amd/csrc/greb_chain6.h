@@ -1,15 +1,16 @@
-// greb_chain6.h -- the sub-cycled zonal sweep of a latitude circle held 6 points per lane, as 36 instructions.
+// greb_chain6.h -- the sub-cycled zonal sweep of a latitude circle held 6 points per lane, as 33 + 3 instructions.
 //
 // The circle is either the whole wavefront (64 lanes x 6 = 384 points: the 384x192 grid, one chain per wave) or one
 // DPP row of 16 lanes (16 x 6 = 96 points: the 96x48 grid, four independent chains per wave -- the fused engine's
 // polar rows).  The long polar chains (src/greb.f90:651-719, :837-911; at 384x192 up to 225 -- 1 800 for
 // kappa < 7.27e5 -- DEPENDENT sweeps per diffusion call) are latency: a lone wavefront issues one
-// vector instruction per ~5 cycles whatever the instruction is: the chain's latency is its instruction count.  FAST
+// vector instruction per 4.0 cycles whatever the instruction is (tools/ubench/chain_rate.hip): the chain's latency is
+// its instruction count -- 33 for the sweep, 3 more where the clamp minimum has to be carried along (chain_run6).  FAST
 // arithmetic only (greb_stencil.h: chain_lon_regs): during a chain the weights, the row constant and the wind are
 // fixed, so the increment of point c is a fixed linear form in the six differences around it,
 //     d[i] = sum_m K[i][m] * e[i+m],  e[j] = T[j+1] - T[j]  over the window T[0..11] = (prev lane's o[3..5], o[0..5],
 //     next lane's o[0..2]),           n[i] = o[i] + d[i],   mn = min_i n[i]  (the clamp test, see chain_sweeps6).
-// What makes it 36 instructions instead of the compiler's 65 for the same arithmetic:
+// What makes it 33 (+ 3 for the minimum) instructions instead of the compiler's 65 for the same arithmetic:
 //   * points are paired (i, i+3): (o0,o3), (o1,o4), (o2,o5).  Term m of the pair then needs (e[i+m], e[i+m+3]) -- one
 //     alignment only, so e lives in four register pairs E2..E5 = (e2,e5), (e3,e6), (e4,e7), (e5,e8), two of them a
 //     single v_pk_add of the point pairs, and 12 of the 36 multiply-adds are v_pk_fma_f32 (same issue slot as a scalar
