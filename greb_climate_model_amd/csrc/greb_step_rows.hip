@@ -29,6 +29,8 @@ namespace greb {
 namespace {
 using namespace rows;
 
+typedef const __attribute__((address_space(4))) unsigned long long* cull_ptr; // scalar-loadable: immutable during a launch
+typedef __attribute__((address_space(4))) RowTables crow_tables;
 constexpr int kRing = 4;   // landing slots of the tracer/weight rows: a row waits here until the window takes it
 constexpr unsigned kOutBase = 0, kRingBase = kRowB, kWindBase = kRowB + kRing * kSlotB;
 constexpr unsigned kStepLdsB = kWindBase + 2 * kSlotB; // 19.5 KB: eight wavefronts per CU
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
     const unsigned long long t = a.head[blockIdx.x];
     fld = __builtin_amdgcn_readfirstlane((int)(unsigned)t); task_rows = __builtin_amdgcn_readfirstlane((int)(t >> 32));
   } else {
-    const unsigned long long t = *reinterpret_cast<const unsigned long long*>(a.tasks + blockIdx.x);
+    const unsigned long long t = *(cull_ptr)(a.tasks + blockIdx.x);
     fld = __builtin_amdgcn_readfirstlane((int)(unsigned)t); task_rows = __builtin_amdgcn_readfirstlane((int)(t >> 32));
   }
 #ifdef GREB_TUNING
@@ -96,7 +98,11 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
   const int k0 = task_rows & 0xff, k1 = (task_rows >> 8) & 0x1ff, ny = a.ny;
   const unsigned lane = threadIdx.x;
   const int member = fld >> 1, tracer = fld & 1;
-  const RowTables& tab = a.tabs[tab_idx]; // (in the task word: one dependent memory latency less before the first row)
+  // the row table through the CONSTANT address space: it is immutable for the life of the launch, and only that lets the
+  // compiler select scalar loads (s_load) behind the kernel's own global stores and LDS-DMA -- as a generic pointer the
+  // per-row constants were four global_load_dword + s_waitcnt vmcnt(0) in the row loop: every row drained the whole
+  // LDS-DMA ring (the rows requested three ahead, the winds), which the hand-counted waits exist to avoid
+  const crow_tables& tab = *(const crow_tables*)(a.tabs + tab_idx); // (index in the task word: one dependent latency less)
   const size_t np = (size_t)kNx * ny;
   const float* Xf = a.X + (size_t)fld * np;
   const float* wf = a.W2 + (size_t)tracer * np;

@@ -136,6 +136,60 @@ def test_fast_kernels_at_a_register_cliff_stay_off_scratch(code_objects):
                 assert not [i for i in body if i.startswith("scratch_")], name[:80]
 
 
+def test_row_strip_kernels_load_their_constants_through_the_scalar_cache(code_objects):
+    """The row-strip kernels count vmcnt by hand (greb_rows.h): LDS-DMA and stores only.  A plain vector load in there
+    -- the per-row constants of step_rows_kernel once were four global_load_dword + s_waitcnt vmcnt(0) per row, because
+    the table was read through a generic pointer behind the kernel's own stores -- drains the whole LDS-DMA ring every
+    row.  Tables and task words must come by s_load (constant address space) or by value."""
+    seen = 0
+    for path in code_objects:
+        for name, body in _functions(path).items():
+            if not re.search(r"(step_rows_kernel|dif_rows_kernel|circ_rows_kernel)<", name) or name.startswith("__"):
+                continue
+            seen += 1
+            bad = [i for i in body if re.match(r"^(global_load_(dword|dwordx2|dwordx3|dwordx4|ubyte|ushort|sbyte|sshort)|flat_load\S*|buffer_load\S*)\s", i)]
+            assert not bad, (name[:90], bad[:4])
+            if "step_rows_kernel<false" in name or "circ_rows_kernel<false" in name:
+                assert sum(i.startswith("s_load_dword") for i in body) >= 8, name[:90]  # arguments, task, row constants
+    assert seen >= 5, seen
+
+
+def test_pending_lds_reads_are_left_alone_until_their_wait(code_objects):
+    """greb_rows.h splits a row read into read_pair_issue (six ds_read_b64) and read_pair_finish (s_waitcnt lgkmcnt(0))
+    with the window shift between them, in two asm statements: nothing but register allocation keeps the compiler from
+    copying a destination register in between, which would read data that has not arrived.  Checked on the built code:
+    between a ds_read_* and the next lgkmcnt(0) wait no instruction reads or writes its destination VGPRs."""
+    checked = 0
+    for path in code_objects:
+        for name, body in _functions(path).items():
+            if "_rows_kernel<" not in name or name.startswith("__"):
+                continue
+            pending = set()
+            for ins in body:
+                if ins.startswith("s_waitcnt") and ("lgkmcnt(0)" in ins or ins.strip() == "s_waitcnt 0"):
+                    pending = set()
+                    continue
+                if re.match(r"^s_waitcnt\s+vmcnt\(\d+\)\s+lgkmcnt\(0\)", ins) or "lgkmcnt(0)" in ins:
+                    pending = set()
+                    continue
+                m = re.match(r"^(\S+)\s+(.*)$", ins)
+                regs = set()
+                if m:
+                    for op in re.split(r"[,\s]+", m.group(2)):
+                        regs |= _vregs(op.strip())
+                if pending and not ins.startswith("ds_read"):
+                    assert not (regs & pending), (name[:80], ins, sorted(regs & pending))
+                if ins.startswith("ds_read") or ins.startswith("ds_bpermute") or ins.startswith("ds_permute"):
+                    if pending:  # a second read may not overwrite or consume a pending one either
+                        srcs = set()
+                        for op in re.split(r"[,\s]+", m.group(2))[1:]:
+                            srcs |= _vregs(op.strip())
+                        assert not (srcs & pending), (name[:80], ins)
+                    pending |= _written(ins) if ins.startswith("ds_read") else _vregs(re.split(r"[,\s]+", m.group(2))[0])
+                    checked += 1
+    assert checked > 100, checked
+
+
 def test_every_device_header_is_a_build_dependency():
     """An edit to any csrc/*.h must trigger a rebuild (a stale libgreb_hip.so once shipped after an edit to
     greb_chain6.h alone)."""
