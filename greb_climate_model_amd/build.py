@@ -16,8 +16,8 @@ LIB = os.path.join(PKG, "libgreb_hip.so")
 # the same sources with -DGREB_TUNING: the timing-experiment knobs of tools/ (GREB_DEBUG_SKIP, GREB_DEBUG_NSUB, ...)
 # exist only in this variant; the release library above never reads the environment
 LIB_TUNING = os.path.join(PKG, "libgreb_hip_tuning.so")
-SOURCES = ["greb_engine.cpp", "greb_kernels.hip", "greb_member.hip", "greb_ensemble.hip", "greb_rows.hip", "greb_step_rows.hip"]
-HEADERS = ["greb_device.h", "greb_kernels.h", "greb_stencil.h", "greb_chain6.h", "greb_rows.h", "greb_pair.h", "greb_physics_step.h", os.path.join(ROOT, "include", "greb_engine.h")]
+SOURCES = ["greb_engine.cpp", "greb_kernels.hip", "greb_member.hip", "greb_ensemble.hip", "greb_rows.hip", "greb_step_rows.hip", "greb_circ_rows.hip"]
+HEADERS = ["greb_device.h", "greb_kernels.h", "greb_stencil.h", "greb_chain6.h", "greb_rows.h", "greb_step_strip.h", "greb_step_order.h", "greb_pair.h", "greb_physics_step.h", os.path.join(ROOT, "include", "greb_engine.h")]
 # -O2: measured 1.4 % faster than -O3 on the fused member kernel (3 790 vs 3 735 yr/s), equal elsewhere
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                "-I" + os.path.join(ROOT, "include")]
@@ -30,7 +30,8 @@ def hipcc() -> str:
 # per-source extra flags.  greb_rows.hip: the SLP vectoriser packs the scalar stencil of the row-strip kernel into
 # v_pk_* instructions whose halves it then has to shuffle together (319 v_mov against 113, 156 VGPRs against 120: one
 # wave per SIMD less); a packed fp32 instruction occupies the pipe as long as its two halves would, so nothing is gained.
-EXTRA_FLAGS = {"greb_rows.hip": ["-fno-slp-vectorize"], "greb_step_rows.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"greb_rows.hip": ["-fno-slp-vectorize"], "greb_step_rows.hip": ["-fno-slp-vectorize"],
+               "greb_circ_rows.hip": ["-fno-slp-vectorize"]}
 OBJ_DIR = os.path.join(PKG, "csrc", "_obj")
 
 

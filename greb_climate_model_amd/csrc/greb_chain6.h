@@ -352,8 +352,8 @@ __device__ __forceinline__ float chain_wave_extreme(float x) { // over the 64 la
   return op(op(a, b), op(c, d));
 }
 constexpr int kChainPlainMinSweeps = 64, kChainPlainMaxSweeps = 2048; // (the test costs about three sweeps)
-__device__ __forceinline__ bool chain_stays_positive(const float (&T)[6], const float (&K)[6][6], int time2) {
-  if (time2 < kChainPlainMinSweeps || time2 > kChainPlainMaxSweeps) return false;
+// ... its two halves: what depends on the coefficients alone (every a_j >= 0 with the centre margin, in every lane) ...
+__device__ __forceinline__ bool chain_coefficients_convex(const float (&K)[6][6]) {
   // the smallest of the seven weights a_j, the centre one less its margin (the sign of an fp32 difference is exact);
   // branch-free: written with && the 42 conditions become 42 exec-mask branches, 2 600 cycles
   float slack = __builtin_inff();
@@ -363,8 +363,27 @@ __device__ __forceinline__ bool chain_stays_positive(const float (&T)[6], const 
     slack = fminf(fminf(slack, K[i][5]), fminf(K[i][3] - K[i][4], K[i][4] - K[i][5]));
     slack = fminf(slack, (0.75f + K[i][2]) - K[i][3]);
   }
+  return __builtin_amdgcn_ballot_w64(!(slack >= 0.f)) == 0; // wave-uniform
+}
+// ... and what depends on the row: 0 < min, max <= 64 min
+__device__ __forceinline__ bool chain_range_positive(const float (&T)[6]) {
+  const float lo = chain_wave_extreme<false>(fminf(fminf(fminf(T[0], T[1]), fminf(T[2], T[3])), fminf(T[4], T[5])));
+  const float hi = chain_wave_extreme<true>(fmaxf(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])), fmaxf(T[4], T[5])));
+  return lo >= 1e-30f && hi <= 64.f * lo;
+}
+__device__ __forceinline__ bool chain_sweeps_plain_range(int time2) { return time2 >= kChainPlainMinSweeps && time2 <= kChainPlainMaxSweeps; }
+__device__ __forceinline__ bool chain_stays_positive(const float (&T)[6], const float (&K)[6][6], int time2) {
+  if (!chain_sweeps_plain_range(time2)) return false;
+  // (a lane whose coefficients fail vetoes through the minimum: one pair of wave reductions for both halves)
+  float slack = __builtin_inff();
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    slack = fminf(fminf(slack, -K[i][0]), fminf(K[i][0] - K[i][1], K[i][1] - K[i][2]));
+    slack = fminf(fminf(slack, K[i][5]), fminf(K[i][3] - K[i][4], K[i][4] - K[i][5]));
+    slack = fminf(slack, (0.75f + K[i][2]) - K[i][3]);
+  }
   float lo = fminf(fminf(fminf(T[0], T[1]), fminf(T[2], T[3])), fminf(T[4], T[5]));
-  lo = fminf(lo, slack >= 0.f ? __builtin_inff() : -1.f); // a lane whose coefficients fail vetoes through the minimum
+  lo = fminf(lo, slack >= 0.f ? __builtin_inff() : -1.f);
   lo = chain_wave_extreme<false>(lo);
   const float hi = chain_wave_extreme<true>(fmaxf(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])), fmaxf(T[4], T[5])));
   return lo >= 1e-30f && hi <= 64.f * lo;

@@ -132,6 +132,9 @@ struct greb_engine {
   struct StepOrder { RowsTask* dev; int n; RowsTask head[kStepHeadTasks]; };
   std::map<int, StepOrder> step_tasks;                      // its launch order, per number of members run
   int cus = 0;                                              // compute units of the device (4 SIMDs each)
+  bool persistent = false;                                  // ... its circulation call in ONE launch (greb_circ_rows.hip)
+  std::map<int, CircOrder> circ_orders;                     // the tasks, flags and abort word of that launch, per members run
+  int slots_granted = -1;                                   // wavefront slots of the device this engine may fill (-1: not asked yet)
   std::vector<Phys> h_phys;
   // model clock
   long long it_flux = 0; // steps done in the flux phase
@@ -181,6 +184,63 @@ int ensure(greb_engine* e, float** buf, size_t* cap, size_t n) {
   return 0;
 }
 
+// The wavefront slots of a device that one-launch circulation calls may fill, across the engines of this process.
+// Such a launch waits inside the kernel for its own tasks, so all of them must be resident at once; two engines driven
+// side by side (ensemble.run_beside: config 5's 62 + 2 members) share the device, and the sum of what they launch must fit.
+// Every 384-wide engine registers with its member count when it is created; an engine's grant is fixed the first time it
+// needs one: its share of the slots by members among the engines registered then, and never more than what the grants
+// already made leave.  An engine that gets too little for its tasks takes one launch per sub-step, which waits for
+// nothing.  (Another PROCESS on the same device is outside this ledger: there the bounded waits turn a launch that is
+// not co-resident into an error, never a hang.)
+struct SlotLedger {
+  std::mutex mu;
+  struct Entry { greb_engine* e; int device, members, granted; };
+  std::vector<Entry> entries;
+} g_slots;
+
+void ledger_register(greb_engine* e) {
+  std::lock_guard<std::mutex> lock(g_slots.mu);
+  g_slots.entries.push_back({e, e->device, e->nm, 0});
+}
+void ledger_release(greb_engine* e) {
+  std::lock_guard<std::mutex> lock(g_slots.mu);
+  for (size_t i = 0; i < g_slots.entries.size(); ++i)
+    if (g_slots.entries[i].e == e) { g_slots.entries.erase(g_slots.entries.begin() + (long)i); break; }
+}
+int ledger_grant(greb_engine* e, int device_slots) {
+  std::lock_guard<std::mutex> lock(g_slots.mu);
+  long long members = 0, taken = 0;
+  SlotLedger::Entry* mine = nullptr;
+  for (auto& x : g_slots.entries) {
+    if (x.device != e->device) continue;
+    members += x.members;
+    if (x.e == e) mine = &x; else taken += x.granted;
+  }
+  if (!mine) return 0;
+  const long long share = (long long)device_slots * mine->members / std::max<long long>(1, members);
+  mine->granted = (int)std::max<long long>(0, std::min<long long>(share, device_slots - taken));
+  return mine->granted;
+}
+
+// after the stream has been synchronised: did a one-launch circulation call give up waiting?
+int check_circulation(greb_engine* e) {
+  for (auto& kv : e->circ_orders) {
+    unsigned d[5] = {0, 0, 0, 0, 0};
+    const int rc = circ_rows_status(kv.second, d);
+    if (rc == -1) {
+      char buf[384];
+      std::snprintf(buf, sizeof(buf),
+                    "circulation launch given up: task %u waited more than %.1f s in sub-step %u for a neighbouring strip "
+                    "(its count read %u, wanted %u) -- the launch was not resident as a whole (another process on the "
+                    "device?); results are invalid, recreate the engine with GREB_F_NO_PERSISTENT",
+                    d[0], kCircSpinTicks / 1e8, d[1], d[2], d[3]);
+      return fail(e, GREB_E_STATE, buf);
+    }
+    if (rc) return fail(e, GREB_E_STATE, "circulation launch: status word unreadable");
+  }
+  return 0;
+}
+
 // One model year (730 steps) for the first `nrun` members, `a` describing that year.
 //   fused layout : one launch of the member kernel
 //   other grids  : 24 fused band sub-steps + 1 point-physics launch per model step
@@ -196,9 +256,23 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
   // STRICT keeps the band kernel (1 member 64.7 against 74.6 us: its two chains per row run one after the other in
   // one wave here); GREB_F_ROW_STRIPS takes the strips there too.
   const bool rows = e->step_rows && (e->step_rows_always || !e->strict);
+  // the whole circulation call (its nsub sub-steps) in ONE launch where every task of it can be resident at once ...
+  CircOrder* circ = nullptr;
+  if (rows && e->persistent && a.nsub > 0) {
+    if (e->cus <= 0) HIP_TRY(e, hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, e->device));
+    if (e->slots_granted < 0) e->slots_granted = ledger_grant(e, e->cus * kStepRowsSlotsPerCu);
+    auto it = e->circ_orders.find(nrun);
+    if (it == e->circ_orders.end()) {
+      CircOrder o;
+      HIP_TRY(e, circ_rows_make_order(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, e->slots_granted, &o));
+      it = e->circ_orders.emplace(nrun, o).first;
+    }
+    if (it->second.n > 0) circ = &it->second; // (0: the grant is too small for this many fields)
+  }
+  // ... else one launch per sub-step
   const RowsTask *step_tasks = nullptr, *step_head = nullptr;
   int n_step_tasks = 0;
-  if (rows) {
+  if (rows && !circ) {
     auto it = e->step_tasks.find(nrun);
     if (it == e->step_tasks.end()) {
       RowsTask* dev = nullptr; int n = 0;
@@ -217,6 +291,11 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     const int ityr = (int)((it - 1) % kNT) + 1;
     const size_t off = (size_t)(ityr - 1) * np;
     float *cur = e->Xa, *nxt = e->Xb;
+    if (circ) {
+      HIP_TRY(e, launch_circulation_rows(e->Xa, e->Xb, e->W2, e->uclim + off, e->vclim + off, e->tabs, *circ, e->cus * 4, e->ny,
+                                         a.nsub, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
+      if (a.nsub & 1) cur = e->Xb;
+    } else
     for (int tt = 0; tt < a.nsub; ++tt) {
       if (rows)
         HIP_TRY(e, launch_substep_rows(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, step_tasks,
@@ -400,6 +479,9 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
     e->step_rows = !no_step_rows && n_members < (1 << (kStepFieldBits - 1)) && // (field and table index share a task word)
                    step_rows_supported(e->h_tabs.data(), (int)e->h_tabs.size(), nx, ny);
     e->step_rows_always = (flags & GREB_F_ROW_STRIPS) != 0;
+    static const bool no_persistent = tuning_int("GREB_NO_PERSISTENT", 0) != 0; // -DGREB_TUNING builds only (A/B)
+    e->persistent = e->step_rows && !no_persistent && !(flags & GREB_F_NO_PERSISTENT);
+    if (e->persistent) ledger_register(e);
   }
   return 0;
 }
@@ -413,6 +495,8 @@ int greb_engine_destroy(greb_engine* e) {
                   e->Xa, e->Xb, e->red, e->W2};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   for (auto& kv : e->step_tasks) if (kv.second.dev) (void)hipFree(kv.second.dev);
+  for (auto& kv : e->circ_orders) circ_rows_free_order(&kv.second);
+  if (e->persistent) ledger_release(e);
   for (int i = 0; i < 2; ++i) {
     if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
     if (e->ev_free[i]) (void)hipEventDestroy(e->ev_free[i]);
@@ -445,6 +529,7 @@ int greb_engine_flux_correction(greb_engine* e, int years, float* yearly) {
                                 hipMemcpyDeviceToDevice, e->stream));
   }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (int rc = check_circulation(e)) return rc;
   e->it_flux += (long long)years * kNT;
   if (yearly) {
     HIP_TRY(e, hipMemcpy(yearly, e->yearly_dev, (size_t)e->nm * years * 2 * sizeof(float), hipMemcpyDeviceToHost));
@@ -525,6 +610,7 @@ int greb_engine_run(greb_engine* e, int years, const float* co2_ppm, float* mont
     }
   }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (int rc = check_circulation(e)) return rc;
   e->it_scnr += (long long)years * kNT;
   if (yearly) HIP_TRY(e, hipMemcpy(yearly, e->yearly_dev, nm * years * 2 * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
@@ -704,6 +790,26 @@ int greb_substep_launch_order(const greb_params* p, int nx, int ny, int n_member
   step_rows_tasks(tabs.data(), idx.data(), n_members, ny, 256 * kStepRowsSlotsPerCu, tasks); // an MI355X: 256 CUs
   for (size_t i = 0; i < tasks.size() && (int)i < capacity; ++i) {
     field[i] = tasks[i].field & ((1 << kStepFieldBits) - 1); k0[i] = tasks[i].rows & 0xff; k1[i] = (tasks[i].rows >> 8) & 0x1ff;
+  }
+  return (int)tasks.size();
+}
+
+int greb_circulation_launch_plan(const greb_params* p, int nx, int ny, int n_members, const float* kappa, int slots,
+                                 int* field, int* k0, int* k1, int* chain, int* dep4, int capacity) {
+  if (!p || nx < 12 || (nx & 3) || ny < 5 || ny > kMaxNy || n_members < 1 || slots < 1 || capacity < 0 ||
+      (capacity > 0 && (!field || !k0 || !k1 || !chain || !dep4)))
+    return fail(nullptr, GREB_E_INVALID, "circulation_launch_plan: bad argument");
+  std::vector<RowTables> tabs((size_t)n_members);
+  std::vector<int> idx((size_t)n_members);
+  for (int m = 0; m < n_members; ++m) { compute_row_tables(*p, kappa ? kappa[m] : p->kappa, nx, ny, tabs[m]); idx[m] = m; }
+  if (n_members >= (1 << (kStepFieldBits - 1)) || !step_rows_supported(tabs.data(), n_members, nx, ny)) return 0;
+  std::vector<CircTask> tasks;
+  circ_rows_tasks(tabs.data(), idx.data(), n_members, ny, slots, tasks);
+  if ((int)tasks.size() > slots) return 0;
+  for (size_t i = 0; i < tasks.size() && (int)i < capacity; ++i) {
+    field[i] = tasks[i].field & ((1 << kStepFieldBits) - 1); k0[i] = tasks[i].rows & 0xff; k1[i] = (tasks[i].rows >> 8) & 0x1ff;
+    chain[i] = (tasks[i].rows & kCircChain) != 0;
+    for (int j = 0; j < 4; ++j) dep4[4 * i + j] = tasks[i].dep[j];
   }
   return (int)tasks.size();
 }

@@ -109,6 +109,37 @@ hipError_t step_rows_make_tasks(const RowTables* tabs_host, const int* tab_index
 hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
                                const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, const RowsTask* head_host,
                                int n_tasks, int n_simd, int ny, bool strict, hipStream_t s, bool calm_vapor);
+// greb_circ_rows.hip: the circulation CALL (all its sub-steps, src/greb.f90:546-550) on a 384-wide grid in ONE launch.
+// The strips of a field hand their rows to each other through memory flags, so every task of the launch must be
+// resident at once: the caller passes the wavefront slots it may use and the builder never makes more tasks than that.
+struct CircTask {
+  int field;   // (2 * member + tracer) | the member's row-table index << kStepFieldBits
+  int rows;    // k0 | k1 << 8 | kCircChain: rows [k0, k1)
+  int dep[4];  // the tasks that own rows k0-2, k0-1, k1, k1+1 of the same field (each listed once; -1: none)
+  int issue;   // the builder's cost estimate in cycles (diagnostic)
+  int pad;
+};
+constexpr int kCircChain = 1 << 21;        // the task is ONE row whose zonal chains live in registers for the whole call
+constexpr int kChainTaskMinSweeps = 64;    // rows with at least this many dependent diffusion sweeps become chain tasks
+constexpr unsigned kCircSpinTicks = 100u * 1000u * 1000u; // a strip waits at most this long for a neighbour: 1 s of the 100 MHz clock
+void circ_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members, int ny, int n_slots,
+                     std::vector<CircTask>& tasks);
+struct CircOrder {
+  CircTask* tasks = nullptr;  // device
+  unsigned* flags = nullptr;  // device, [n]: sub-steps completed by each task since the order was made
+  unsigned* ctrl = nullptr;   // device, [8]: [0] abort (sticky), [1] task, [2] sub-step, [3] flag seen, [4] flag wanted
+  int n = 0;
+  unsigned epoch = 0;         // what every flag reads between two launches
+};
+hipError_t circ_rows_make_order(const RowTables* tabs_host, const int* tab_index_host, int n_members, int ny, int n_slots,
+                                CircOrder* out);
+void circ_rows_free_order(CircOrder* o);
+// X[0] / X[1]: sub-step s reads X[s & 1] and writes X[(s + 1) & 1]; the result is in X[nsub & 1]
+hipError_t launch_circulation_rows(float* X0, float* X1, const float* W2, const float* u, const float* v,
+                                   const RowTables* tabs_dev, CircOrder& order, int n_simd, int ny, int nsub, bool strict,
+                                   hipStream_t s, bool calm_vapor);
+// after the stream has been synchronised: 0, or -1 with the strip that gave up waiting in msg[0..4] (ctrl[1..5])
+int circ_rows_status(const CircOrder& o, unsigned* diag5);
 hipError_t launch_advection(const float* T1, const float* wz, const float* u, const float* v, float* dX,
                             const RowTables* tab_dev, int nx, int ny, int batch, bool strict, hipStream_t s);
 // 24 sub-steps; 96x48 uses the fused LDS loop of the engine, other grids launch per sub-step

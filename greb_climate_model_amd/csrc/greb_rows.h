@@ -29,6 +29,12 @@ __device__ __forceinline__ void glds16(const float* g, lfloat* l) {
   __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 16, 0, AUX);
 }
 
+// four bytes per ACTIVE lane, lane l to l[l] (flag words polled without holding a VGPR across the wait)
+__device__ __forceinline__ void glds4(const unsigned* g, lfloat* l) {
+  __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 4, 0, 16 /* sc1: agent scope */);
+  asm volatile("" ::: "memory");
+}
+
 // The hand-counted vmcnt scheme needs the vector-memory operations in PROGRAM order: a later LDS-DMA or store scheduled
 // ahead of an earlier one would be counted as younger than it is, and a counted wait could then return before the row
 // it waits for has landed.  Nothing emitted, the compiler just may not move memory operations across it.

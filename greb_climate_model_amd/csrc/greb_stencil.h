@@ -243,6 +243,31 @@ __device__ __forceinline__ float wave_from_next(float x) { // lane l <- lane l+1
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x134 /* wave_rol:1 */, 0xf, 0xf, false));
 }
 
+// FAST: during a chain the weights, the row constant and the wind are fixed, so the increment of point c is a fixed
+// linear form in the six differences around it, d(c) = sum_m K[c][m] * e[c-3+m] with e[j] = T[j+1] - T[j]; w = the lane's P
+// weights with three halo points on either side, u its winds.  The coefficients depend on nothing that changes between
+// the sub-steps of a circulation call (greb_circ_rows.hip builds them once per call).
+template <int P>
+__device__ __forceinline__ void chain_coefficients(const float (&w)[P + 6], const float (&u)[P], float cc, bool is_adv,
+                                                   bool bug_lane, float (&K)[P][6]) {
+  const float cs = cc * 0.05f;
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int c = 3 + i;
+    if (is_adv) { // -up*(10 Pp[c] + 4 Pp[c+1] + Pp[c+2]) - um*(10 Pm[c-1] + 4 Pm[c-2] + Pm[c-3]), :845-851
+      const float um = cs * split_m(u[i]), up = cs * split_p(u[i]);
+      K[i][0] = -um * w[c - 3]; K[i][1] = -4.f * um * w[c - 2]; K[i][2] = -10.f * um * w[c - 1];
+      K[i][3] = -10.f * up * w[c + 1]; K[i][4] = -4.f * up * w[c + 2]; K[i][5] = -up * w[c + 3];
+      if (i == P - 3 && bug_lane) { // :881: the 4* term vanishes, the 1* term is w(1)*(T(xdim-1)-T(1)) = w[c+3]*(e[c+1]+e[c+2])
+        K[i][4] = -up * w[c + 3]; K[i][5] = -up * w[c + 3];
+      }
+    } else { // 6(Pp[c] - Pm[c-1]) + 3(Pp[c+1] - Pm[c-2]) + (Pp[c+2] - Pm[c-3]), :595-600 in edge-flux form
+      K[i][0] = -cs * w[c - 3]; K[i][1] = -3.f * cs * w[c - 2]; K[i][2] = -6.f * cs * w[c - 1];
+      K[i][3] = 6.f * cs * w[c + 1]; K[i][4] = 3.f * cs * w[c + 2]; K[i][5] = cs * w[c + 3];
+    }
+  }
+}
+
 constexpr int kChainPrioSweeps = 32;
 // the chain on a register window: T[0..P+5] / w[0..P+5] = the lane's P points with three halo points on either side,
 // u[0..P-1] the zonal wind of its points; the result (T1h) is left in T[3..P+2]
@@ -254,24 +279,7 @@ __device__ __forceinline__ void chain_window(float (&T)[P + 6], const float (&w)
   // 37.8 us per sub-step launch for one member)
   if (prio && time2 >= kChainPrioSweeps) __builtin_amdgcn_s_setprio(3);
   float K[P][6]; // FAST: d(c) = sum_m K[c][m] * e[c-3+m]
-  if (!STRICT) {
-    const float cs = cc * 0.05f;
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-      const int c = 3 + i;
-      if (is_adv) { // -up*(10 Pp[c] + 4 Pp[c+1] + Pp[c+2]) - um*(10 Pm[c-1] + 4 Pm[c-2] + Pm[c-3]), :845-851
-        const float um = cs * split_m(u[i]), up = cs * split_p(u[i]);
-        K[i][0] = -um * w[c - 3]; K[i][1] = -4.f * um * w[c - 2]; K[i][2] = -10.f * um * w[c - 1];
-        K[i][3] = -10.f * up * w[c + 1]; K[i][4] = -4.f * up * w[c + 2]; K[i][5] = -up * w[c + 3];
-        if (i == P - 3 && bug_lane) { // :881: the 4* term vanishes, the 1* term is w(1)*(T(xdim-1)-T(1)) = w[c+3]*(e[c+1]+e[c+2])
-          K[i][4] = -up * w[c + 3]; K[i][5] = -up * w[c + 3];
-        }
-      } else { // 6(Pp[c] - Pm[c-1]) + 3(Pp[c+1] - Pm[c-2]) + (Pp[c+2] - Pm[c-3]), :595-600 in edge-flux form
-        K[i][0] = -cs * w[c - 3]; K[i][1] = -3.f * cs * w[c - 2]; K[i][2] = -6.f * cs * w[c - 1];
-        K[i][3] = 6.f * cs * w[c + 1]; K[i][4] = 3.f * cs * w[c + 2]; K[i][5] = cs * w[c + 3];
-      }
-    }
-  }
+  if (!STRICT) chain_coefficients<P>(w, u, cc, is_adv, bug_lane, K);
   if (STRICT) {
     for (int tt = 0; tt < time2; ++tt) {
       if (tt > 0) { // refresh the halo from the neighbours' new values

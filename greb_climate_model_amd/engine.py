@@ -55,7 +55,7 @@ EXPORTS = ["greb_params_default", "greb_engine_create", "greb_engine_flux_correc
            "greb_advection_batched", "greb_circulation_batched", "greb_diffusion_batched_dev",
            "greb_engine_point_physics", "greb_log_exp_switches", "greb_engine_set_experiment",
            "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev", "greb_engine_set_state", "greb_release_caches", "greb_diffusion_launch_order",
-           "greb_substep_launch_order"]
+           "greb_substep_launch_order", "greb_circulation_launch_plan"]
 
 
 def _check(rc: int, h=None):
@@ -87,7 +87,7 @@ class Engine:
 
     def __init__(self, inp: workload.Inputs, params: abi.GrebParams | None = None, n_members: int = 1,
                  overrides=None, device: int = 0, strict: bool = False, multilaunch: bool = False,
-                 row_strips: bool = False):
+                 row_strips: bool = False, persistent: bool = True):
         L = lib()
         self.params = params or params_default()
         self.nx, self.ny, self.np, self.nm = inp.nx, inp.ny, inp.nx * inp.ny, n_members
@@ -101,7 +101,8 @@ class Engine:
         self.h = C.c_void_p()
         rc = L.greb_engine_create(C.byref(self.params), inp.nx, inp.ny, C.byref(fields), n_members, ov, device,
                                   (abi.F_STRICT if strict else 0) | (abi.F_MULTILAUNCH if multilaunch else 0) |
-                                 (abi.F_ROW_STRIPS if row_strips else 0), C.byref(self.h))
+                                 (abi.F_ROW_STRIPS if row_strips else 0) | (0 if persistent else abi.F_NO_PERSISTENT),
+                                  C.byref(self.h))
         if rc != 0:
             msg = L.greb_engine_last_error(self.h).decode()
             if self.h:
@@ -236,6 +237,23 @@ def substep_launch_order(params, nx, ny, n_members, kappa=None):
     if n:
         ptr = [a.ctypes.data_as(C.POINTER(C.c_int)) for a in out]
         assert f(C.byref(params), nx, ny, n_members, kp, *ptr, n) == n
+    return out
+
+
+def circulation_launch_plan(params, nx, ny, n_members, kappa=None, slots=2048):
+    """Host-only diagnostic: the tasks of the one-launch circulation call for `slots` wavefront slots: arrays
+    (field, k0, k1, chain, dep[n][4]) (include/greb_engine.h: greb_circulation_launch_plan)."""
+    params = params if params is not None else params_default()
+    kap = None if kappa is None else np.ascontiguousarray(kappa, np.float32)
+    kp = None if kap is None else kap.ctypes.data_as(C.POINTER(C.c_float))
+    f = lib().greb_circulation_launch_plan
+    n = f(C.byref(params), nx, ny, n_members, kp, slots, None, None, None, None, None, 0)
+    if n < 0:
+        _check(n)
+    out = [np.zeros(n, np.int32) for _ in range(4)] + [np.zeros((n, 4), np.int32)]
+    if n:
+        ptr = [a.ctypes.data_as(C.POINTER(C.c_int)) for a in out]
+        assert f(C.byref(params), nx, ny, n_members, kp, slots, *ptr, n) == n
     return out
 
 

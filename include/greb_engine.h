@@ -82,11 +82,16 @@ typedef struct greb_member_overrides {
                                  where the fused one-CU-per-member kernel applies (96x48); grids that
                                  do not fit one CU, e.g. 384x192, always use it */
 
-#define GREB_F_ROW_STRIPS 4u /* 384-wide grids: take the row-strip form of the circulation sub-step
-                                (greb_step_rows.hip: one wavefront per strip of rows, no workgroup barrier) for every
-                                member count and in STRICT arithmetic too.  Default: FAST with at most 8 members,
-                                where it is the faster form (one member: 24.0 against 25.1 us per sub-step launch;
-                                from ~16 members on the band kernels win) */
+#define GREB_F_ROW_STRIPS 4u /* 384-wide grids: FAST arithmetic takes the row-strip form of the circulation
+                                (greb_step_rows.hip: one wavefront per strip of rows, no workgroup barrier) by default
+                                at every member count; this flag extends it to STRICT arithmetic, which otherwise keeps
+                                the band kernel (greb_kernels.hip: sweep_kernel<fused>).  The two are bit-identical in
+                                STRICT (tests/test_gpu_parity.py::test_row_strip_substep_equals_band_kernel_strict) */
+#define GREB_F_NO_PERSISTENT 8u /* 384-wide grids: one launch per circulation SUB-STEP (24 per model step) instead of
+                                   the default one launch per circulation CALL, whose strips hand their rows to each other
+                                   through memory flags and therefore need every strip of the launch resident at once
+                                   (asserted against the device's wavefront slots; engines created while another engine
+                                   of this process holds the slots of the device fall back to this form by themselves) */
 
 typedef struct greb_engine greb_engine;
 
@@ -193,6 +198,16 @@ int greb_diffusion_launch_order(const greb_params* p, int nx, int ny, int batch,
  * (256 compute units) gets: at most one task per wavefront slot (2 048), tasks i and i + 1 024 share a SIMD. */
 int greb_substep_launch_order(const greb_params* p, int nx, int ny, int n_members, const float* kappa, int* field, int* k0,
                               int* k1, int capacity);
+
+/* The tasks of the engine's ONE-LAUNCH circulation call (greb_circ_rows.hip; src/greb.f90:546-550: the 24 sub-steps of a
+ * `circulation` call inside one kernel) for `slots` wavefront slots: per task the field (2 * member + tracer), its rows
+ * [k0, k1), whether it is a chain task (one row whose zonal chains stay in registers for the whole call) and up to four
+ * dependencies dep4[4 * i .. 4 * i + 3] (task indices, -1 = none): the owners of rows k0-2, k0-1, k1, k1+1 of the same
+ * field, whose completed sub-step s - 1 a task waits for before it starts sub-step s.  Host-only (no GPU call).
+ * Returns the number of tasks -- never more than `slots` -- or 0 when the grid does not take this kernel or the slots
+ * do not suffice (the engine then launches once per sub-step), or < 0. */
+int greb_circulation_launch_plan(const greb_params* p, int nx, int ny, int n_members, const float* kappa, int slots,
+                                 int* field, int* k0, int* k1, int* chain, int* dep4, int capacity);
 
 /* Point physics of one step for a batch of columns sets (tests): SWradiation :367-403,
  * LWradiation :407-434, hydro :438-469, deep_ocean :495-525, seaice :472-492 evaluated by the

@@ -391,17 +391,52 @@ def test_row_strip_substep_equals_band_kernel_strict(eng_mod, inputs384):
     g = load_golden("g384_physpar.npz")
     ov = [dict(zip(("da_ice", "a_no_ice", "a_cloud", "kappa"), map(float, g["overrides"][m]))) for m in (0, 1, 4)]
     out = []
-    for strips in (False, True):
-        e = eng_mod.Engine(inputs384, abi.default_params(ipx=380, ipy=152), n_members=3, overrides=ov, strict=True, row_strips=strips)
+    # band kernel | strips, one launch per sub-step | strips, one launch per circulation call (greb_circ_rows.hip: the 24
+    # sub-steps in the kernel, rows handed from strip to strip through memory flags; chain rows resident in registers)
+    for strips, persistent in ((False, False), (True, False), (True, True)):
+        e = eng_mod.Engine(inputs384, abi.default_params(ipx=380, ipy=152), n_members=3, overrides=ov, strict=True,
+                           row_strips=strips, persistent=persistent)
         e.flux_correction(1)
         mon, yr = e.run(1, 680.0)
         st = [e.state(m) for m in range(3)]
         e.close()
         out.append((mon, yr, st))
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-    for a, b in zip(out[0][2], out[1][2]):
-        assert np.array_equal(a, b)
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1])
+        for a, b in zip(out[0][2], other[2]):
+            assert np.array_equal(a, b)
     assert np.isfinite(out[1][0]).all()
+
+
+@pytest.mark.parametrize("members", [1, 5, 40])
+def test_one_launch_circulation_equals_one_launch_per_substep_fast(eng_mod, inputs384, members):
+    """FAST arithmetic, the product path: the circulation call as ONE launch (src/greb.f90:546-550 as the reference runs
+    it: 24 sub-steps inside one call) against one launch per sub-step.  Row by row the two run the same instruction
+    sequences on the same operands -- what differs is who hands which row to whom and when (kernel boundaries there;
+    agent-scope stores, flags and L1-bypassing LDS-DMA here; chain rows that never leave their registers) -- so a year of
+    both, flux corrections included, must agree BIT FOR BIT: any row read before its owner had written it, or from a stale
+    cache line, would show.  1 member: every task has a SIMD of its own; 5: own diffusivities incl. the 1 800-sweep
+    member, chain tasks next to each other; 40: tasks share SIMDs."""
+    from greb_climate_model_amd import abi
+    g = load_golden("g384_physpar.npz")
+    ov = None
+    if members > 1:
+        ov = [dict(zip(("da_ice", "a_no_ice", "a_cloud", "kappa"), map(float, g["overrides"][m % 5]))) for m in range(members)]
+    if members == 40:
+        for o in ov:
+            o["kappa"] = max(o["kappa"], 7.4e5)  # (the 1 800-sweep rows are in the 5-member case; here: a short run)
+    out = []
+    for persistent in (False, True):
+        e = eng_mod.Engine(inputs384, abi.default_params(ipx=380, ipy=152), n_members=members, overrides=ov, persistent=persistent)
+        yf = e.flux_correction(1)
+        mon, yr = e.run(1, 680.0)
+        st = [e.state(m) for m in range(members)]
+        e.close()
+        out.append((mon, yr, yf, st))
+    assert np.isfinite(out[1][0]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    for a, b in zip(out[0][3], out[1][3]):
+        assert np.array_equal(a, b)
 
 
 def test_row_strip_substep_with_experiment_switches(eng_mod, inputs384):

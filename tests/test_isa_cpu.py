@@ -148,10 +148,12 @@ def test_row_strip_kernels_load_their_constants_through_the_scalar_cache(code_ob
                 continue
             seen += 1
             bad = [i for i in body if re.match(r"^(global_load_(dword|dwordx2|dwordx3|dwordx4|ubyte|ushort|sbyte|sshort)|flat_load\S*|buffer_load\S*)\s", i)]
+            if "circ_rows_kernel<" in name:  # its flag polls: one dword per dependency, agent scope, waited for where they are issued
+                bad = [i for i in bad if not re.match(r"^global_load_dword v\d+, v\[\d+:\d+\], off sc1$", i)]
             assert not bad, (name[:90], bad[:4])
             if "step_rows_kernel<false" in name or "circ_rows_kernel<false" in name:
                 assert sum(i.startswith("s_load_dword") for i in body) >= 8, name[:90]  # arguments, task, row constants
-    assert seen >= 5, seen
+    assert seen >= 7, seen
 
 
 def test_pending_lds_reads_are_left_alone_until_their_wait(code_objects):

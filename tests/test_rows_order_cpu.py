@@ -71,3 +71,49 @@ def test_substep_order_is_a_partition_in_one_round(n_members):
         assert n > 1900  # the slots are used
         assert not (long_chain[: n - 1024] & long_chain[1024:]).any()
     assert len(engine.substep_launch_order(p, 96, 48, 2)[0]) == 0  # other grids keep the band kernels
+
+
+@pytest.mark.parametrize("n_members,slots", [(1, 2048), (3, 2048), (8, 2048), (40, 2048), (62, 2048), (62, 1984), (2, 64), (5, 200)])
+def test_circulation_plan_is_a_partition_with_every_dependency_in_it(n_members, slots):
+    """The one-launch circulation call (greb_circ_rows.hip: circ_rows_tasks; src/greb.f90:546-550): every row of every
+    field is owned by exactly one task; there are never more tasks than the wavefront slots given (the launch waits inside
+    the kernel for its own tasks: all of them must be resident at once); rows with >= 64 dependent diffusion sweeps are
+    chain tasks of one row; and the dependency table is complete and minimal: a task lists exactly the owners of the rows
+    k0-2, k0-1, k1, k1+1 of ITS field that are not itself -- each exists, each once, all in the same launch."""
+    p = abi.default_params()
+    kappa = (np.float32(8e5) * (1 + 0.05 * np.sin(np.arange(n_members)))).astype(np.float32)
+    if n_members == 2:
+        kappa[:] = 7.2e5  # config 5's second engine: 1 800-sweep polar rows (src/greb.f90:652-654)
+    field, k0, k1, chain, dep = engine.circulation_launch_plan(p, 384, 192, n_members, kappa, slots)
+    n = len(field)
+    assert 0 < n <= slots
+    owner = -np.ones((2 * n_members, 192), np.int64)
+    for i, (f, a, b) in enumerate(zip(field, k0, k1)):
+        assert 0 <= a < b <= 192 and 0 <= f < 2 * n_members
+        assert (owner[f, a:b] == -1).all()
+        owner[f, a:b] = i
+    assert (owner >= 0).all()
+    for i in range(n):
+        want = set()
+        for k in (k0[i] - 2, k0[i] - 1, k1[i], k1[i] + 1):
+            if 0 <= k < 192 and owner[field[i], k] != i:
+                want.add(int(owner[field[i], k]))
+        got = [int(d) for d in dep[i] if d >= 0]
+        assert len(got) == len(set(got)) and set(got) == want, (i, got, want)
+        assert all(field[d] == field[i] for d in got)
+        if chain[i]:
+            assert k1[i] == k0[i] + 1
+    # which rows are chain tasks follows from the row's own sub-cycle count alone, the same in every field of a table
+    sweeps = {1: 225, 2: 82, 189: 82, 190: 225}
+    for f in range(2 * n_members):
+        rows = sorted(int(k0[i]) for i in range(n) if field[i] == f and chain[i])
+        if n_members != 2:
+            assert rows == sorted(sweeps), (f, rows)
+        else:
+            assert rows == [0, 1, 2, 189, 190, 191], (f, rows)
+
+
+def test_circulation_plan_declines_what_cannot_be_resident():
+    p = abi.default_params()
+    assert len(engine.circulation_launch_plan(p, 384, 192, 62, None, 300)[0]) == 0   # 124 fields x >= 5 tasks
+    assert len(engine.circulation_launch_plan(p, 96, 48, 2, None, 2048)[0]) == 0     # other grids: other kernels
