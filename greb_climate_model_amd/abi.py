@@ -12,6 +12,7 @@ F_STRICT = 1
 F_MULTILAUNCH = 2
 F_ROW_STRIPS = 4
 F_NO_PERSISTENT = 8
+F_PERSISTENT = 16
 RUN_DEVICE_OUT = 1
 # sensitivity-experiment switches, GREB_X_* of include/greb_engine.h
 X_NO_ICE, X_NO_HYDRO, X_NO_DEEP_OCEAN, X_LW_LINEAR_VAPOR = 1, 2, 4, 8

@@ -87,13 +87,20 @@ __device__ __forceinline__ bool deps_ready(unsigned seen, unsigned want, unsigne
   aborted = (bad & 16ull) != 0;
   return bad == 0;
 }
+#ifdef GREB_TUNING
+#define GREB_CIRC_WAITED(t0) if (a.timeline && lane == 0) a.timeline[3 * gridDim.x + blockIdx.x] += __builtin_amdgcn_s_memrealtime() - (t0)
+#define GREB_CIRC_DRAINED(t0) if (a.timeline && lane == 0) a.timeline[4 * gridDim.x + blockIdx.x] += __builtin_amdgcn_s_memrealtime() - (t0)
+#else
+#define GREB_CIRC_WAITED(t0)
+#define GREB_CIRC_DRAINED(t0)
+#endif
 __device__ bool wait_deps(const CircArgs& a, const unsigned* mine, unsigned want, unsigned lane, int s) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
     unsigned seen = lane == 4 ? 0u : want;
     if (mine) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(mine) : "memory");
     bool aborted;
-    if (deps_ready(seen, want, lane, aborted)) return true;
+    if (deps_ready(seen, want, lane, aborted)) { GREB_CIRC_WAITED(t0); return true; }
     if (aborted) return false;
     if (__builtin_amdgcn_s_memrealtime() - t0 > a.spin_ticks) {
       // (what the first unsatisfied lane saw)
@@ -178,7 +185,8 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
   int head = a.chain_head, tail = a.chain_tail;
   if (head + tail + 8 > t2d) { head = 0; tail = 0; }
   const bool prio = a.chains_first != 0; // the long chains issue ahead of whatever shares their SIMD -- unless SIMDs are shared by design
-  bool published = false; // the previous sub-step's count (a wavefront that had to wait publishes before it waits)
+  int fetched = 0;                  // halo(0) .. halo(fetched) have been requested
+  const int last_halo = a.nsub - 1; // ... of halo(0) .. halo(nsub - 1)
   for (int s = 0; s < a.nsub; ++s) {
     float* dst = a.X[(s + 1) & 1] + (size_t)fld * np;
 #ifdef GREB_TUNING
@@ -186,8 +194,10 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
 #endif
     const float (&T0)[6] = Tw[2];
     float Td[6], Ta[6];
-    const bool more = s + 1 < a.nsub;
     // ---- zonal part (:656-717, :842-909): from registers
+#ifdef GREB_TUNING
+    const unsigned long long tz = __builtin_amdgcn_s_memrealtime();
+#endif
     if (prio) __builtin_amdgcn_s_setprio(3);
     if (STRICT) {
       float Tc[12];
@@ -209,9 +219,9 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
         done += n;
       };
       part(head);
-      if (s > 0 && !published) publish(my_flag, a.epoch0 + (unsigned)s, lane);
+      if (s > 0) publish(my_flag, a.epoch0 + (unsigned)s, lane); // sub-step s - 1 has left (its stores were issued `head` sweeps ago)
       part(t2d - head - tail);
-      if (more && mine) glds4(mine, lds + kPollBase / 4);
+      if (fetched < last_halo && mine) glds4(mine, lds + kPollBase / 4);
       part(tail);
 #pragma unroll
       for (int j = 0; j < 6; ++j) Td[j] = Tc[3 + j];
@@ -226,14 +236,38 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
       }
       const bool positive = convex && chain_range_positive(T0);
       if (head > 0) chain_run6<false>(Td, Kd, head, positive);
-      if (s > 0 && !published) publish(my_flag, a.epoch0 + (unsigned)s, lane);
+      if (s > 0) publish(my_flag, a.epoch0 + (unsigned)s, lane); // sub-step s - 1 has left (its stores were issued `head` sweeps ago)
       chain_run6<false>(Td, Kd, t2d - head - tail, positive);
-      if (more && mine) glds4(mine, lds + kPollBase / 4);
+      if (fetched < last_halo && mine) glds4(mine, lds + kPollBase / 4);
       if (tail > 0) chain_run6<false>(Td, Kd, tail, positive);
     }
     __builtin_amdgcn_s_setprio(0);
-    // ---- meridional part and the update: the neighbours' rows of this sub-step are in LDS since the last one
-    drain(); // (the poll words; everything older has long landed)
+    GREB_CIRC_DRAINED(tz); // (a chain task's second tuning counter: the time in its chains, publish included)
+    // ---- the neighbours' rows.  halo(j) = rows r-2 .. r+2 of X[j & 1] once their owners have completed sub-step j - 1;
+    // it is requested as early as the owners allow -- normally one sub-step ahead, during the chains -- and NEEDED only
+    // here, so a neighbour may lag this task by up to a sub-step before anybody waits (tasks that share a SIMD with
+    // streaming strips are not in lock step with their neighbours).  This task's own count was published after the
+    // `head` sweeps above: nothing below can make two neighbouring chain tasks wait for one another.
+    drain(); // the poll words (and every halo requested so far)
+    if (fetched < last_halo) {
+      unsigned seen = lane == 4 ? 0u : a.epoch0 + (unsigned)a.nsub;
+      if (mine) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(lb + kPollBase + 4 * lane) : "memory");
+      const int before = fetched;
+      for (;;) {
+        const int next = fetched + 1;
+        if (next > last_halo || next > s + 1) break;
+        bool aborted;
+        if (!deps_ready(seen, a.epoch0 + (unsigned)next, lane, aborted)) {
+          if (aborted) return;
+          if (next > s) break; // not needed yet: asked for again during the next sub-step's chains
+          if (!wait_deps(a, mine, a.epoch0 + (unsigned)next, lane, s)) return; // needed now
+        }
+        fetch_halo(a.X[next & 1] + (size_t)fld * np, next & 1);
+        fetched = next;
+      }
+      if (before < s) drain(); // this sub-step's own rows were requested only now
+    }
+    // ---- meridional part and the update
     const unsigned hb = lb + kHaloBase + 2 * (s & 1) * kSlotB;
     read_pair(L, hb, Tw[0], Tw[1]);
     read_pair(L, hb + kSlotB, Tw[3], Tw[4]);
@@ -247,22 +281,6 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
     order_fence();
 #pragma unroll
     for (int j = 0; j < 6; ++j) Tw[2][j] = o[j];
-    // ---- the neighbours' rows of the NEXT sub-step: requested now, needed when its chains are through
-    published = false;
-    if (more) {
-      const unsigned want = a.epoch0 + (unsigned)s + 1u; // they have completed sub-step s: their rows of X[(s + 1) & 1] are final
-      unsigned seen = lane == 4 ? 0u : want;
-      if (mine) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(lb + kPollBase + 4 * lane) : "memory");
-      bool aborted;
-      if (!deps_ready(seen, want, lane, aborted)) {
-        if (aborted) return;
-        // not yet: publish this sub-step BEFORE waiting (two chain tasks next to each other wait for one another)
-        publish(my_flag, want, lane);
-        published = true;
-        if (!wait_deps(a, mine, want, lane, s)) return;
-      }
-      fetch_halo(dst, (s + 1) & 1);
-    }
   }
   publish(my_flag, a.epoch0 + (unsigned)a.nsub, lane);
 #ifdef GREB_TUNING
@@ -304,7 +322,11 @@ __global__ __launch_bounds__(64) void circ_rows_kernel(const CircArgs a) {
       if (s > 0 && !wait_deps(a, mine, a.epoch0 + (unsigned)s, lane, s)) return;
       const StripIo io{a.X[s & 1] + (size_t)fld * np, a.W2 + (size_t)tracer * np, a.X[(s + 1) & 1] + (size_t)fld * np, a.u, a.v};
       stream_strip<STRICT, kAuxSc1, true>(lds, io, tab, k0, k1, ny, a.calm_odd && tracer, a.chains_first, lane, st);
+#ifdef GREB_TUNING
+      const unsigned long long td = __builtin_amdgcn_s_memrealtime();
+#endif
       publish(a.flags + blockIdx.x, a.epoch0 + (unsigned)s + 1u, lane);
+      GREB_CIRC_DRAINED(td);
     }
   }
 #ifdef GREB_TUNING
@@ -325,6 +347,7 @@ void circ_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members,
   static const int issue_pct = tuning_int("GREB_STEP_ISSUE_PCT", 54); // -DGREB_TUNING builds only
   static const int wall_pct = tuning_int("GREB_STEP_WALL_PCT", 70);
   static const int chain_min = tuning_int("GREB_CIRC_CHAIN_MIN", kChainTaskMinSweeps);
+  static const int c_alone = tuning_int("GREB_CIRC_CALONE", 0); // experiment: the dearest chain tasks never share a SIMD
   const int n_simd = std::max(1, n_slots / 2);
   auto is_chain = [&](const RowTables& t, int k) { return t.dif_time2[k] >= chain_min; };
   // a chain task: its sweeps and set-up, the meridional part, no streaming
@@ -363,11 +386,15 @@ void circ_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members,
       for (int tr = 0; tr < 2; ++tr)
         for (T x : mine) { x.field = 2 * m + tr; all.push_back(x); }
     }
-    if ((int)all.size() <= n_slots) break;
+    int n_dear = 0;
+    if (c_alone) for (const T& x : all) n_dear += x.chain && x.issue >= 25000;
+    if ((int)all.size() <= n_slots - n_dear) break;
     S += S / 40;
     if (pass == 199) return; // (cannot happen for ny <= 192: one strip per segment is reached long before) -- no tasks: no launch
   }
+  if (c_alone) for (T& x : all) if (x.chain && x.issue >= 25000) x.issue += 1000000; // (sorted first: alone)
   std::stable_sort(all.begin(), all.end(), [](const T& x, const T& y) { return x.issue > y.issue; });
+  if (c_alone) for (T& x : all) if (x.issue >= 1000000) x.issue -= 1000000;
   const int n_all = (int)all.size();
   if (n_all > n_simd) {
     const int m = n_all - n_simd, alone = n_simd - m; // m SIMDs hold a pair
@@ -448,18 +475,22 @@ extern "C" int greb_tuning_circ_stamps(unsigned long long* out, int n) {
   if (!g_circ_stamps || n > 64) return -1;
   return hipMemcpy(out, g_circ_stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
-// [task][start, end] of the LAST launch in 100 MHz ticks, then one hardware id per task; out == null arms it for `capacity` tasks
+// [task][start, end] of the LAST launch in 100 MHz ticks, one hardware id per task, then per task the ticks spent waiting
+// for neighbours and draining stores, summed over the launches since the last read; out == null arms it for `capacity` tasks
 extern "C" int greb_tuning_circ_timeline(unsigned long long* out, int capacity) {
   if (!out) {
     if (g_circ_timeline) (void)hipFree(g_circ_timeline);
     g_circ_timeline = nullptr; g_circ_timeline_cap = 0;
     if (capacity <= 0) return 0;
-    if (hipMalloc(&g_circ_timeline, (size_t)capacity * 3 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMalloc(&g_circ_timeline, (size_t)capacity * 5 * sizeof(unsigned long long)) != hipSuccess) return -1;
     g_circ_timeline_cap = capacity;
-    return hipMemset(g_circ_timeline, 0, (size_t)capacity * 3 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+    return hipMemset(g_circ_timeline, 0, (size_t)capacity * 5 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
   }
   if (!g_circ_timeline || capacity > g_circ_timeline_cap) return -1;
-  return hipMemcpy(out, g_circ_timeline, (size_t)capacity * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+  const hipError_t e = hipMemcpy(out, g_circ_timeline, (size_t)capacity * 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  // (the waits are sums: start the next launch's from zero; capacity must equal the launch's task count, which the layout assumes)
+  (void)hipMemset(g_circ_timeline + 3 * (size_t)capacity, 0, (size_t)capacity * 2 * sizeof(unsigned long long));
+  return e == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -477,7 +508,7 @@ hipError_t launch_circulation_rows(float* X0, float* X1, const float* W2, const 
   a.chain_head = head; a.chain_tail = tail;
 #ifdef GREB_TUNING
   a.stamps = g_circ_stamps;
-  a.timeline = order.n <= g_circ_timeline_cap ? g_circ_timeline : nullptr;
+  a.timeline = order.n == g_circ_timeline_cap ? g_circ_timeline : nullptr;
 #endif
   auto kern = strict ? circ_rows_kernel<true> : circ_rows_kernel<false>;
   hipLaunchKernelGGL(kern, dim3((unsigned)order.n), dim3(64), kStepLdsB, s, a);

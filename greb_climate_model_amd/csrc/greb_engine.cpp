@@ -135,6 +135,10 @@ struct greb_engine {
   bool persistent = false;                                  // ... its circulation call in ONE launch (greb_circ_rows.hip)
   std::map<int, CircOrder> circ_orders;                     // the tasks, flags and abort word of that launch, per members run
   int slots_granted = -1;                                   // wavefront slots of the device this engine may fill (-1: not asked yet)
+  bool persistent_always = false;                           // GREB_F_PERSISTENT: no trial, the one-launch form wherever it can run
+  struct FormTrial { int form = 0; float ms_substep = 0.f, ms_call = 0.f; }; // form: 0 undecided, 1 per sub-step, 2 per call
+  std::map<int, FormTrial> circ_form;                       // which of the two forms runs, per members run
+  hipEvent_t ev_trial[3] = {nullptr, nullptr, nullptr};
   std::vector<Phys> h_phys;
   // model clock
   long long it_flux = 0; // steps done in the flux phase
@@ -269,10 +273,25 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     }
     if (it->second.n > 0) circ = &it->second; // (0: the grant is too small for this many fields)
   }
+  // Which of the two wins depends on how many fields there are and what shares a SIMD with what (one member: 15.1 against
+  // 18.7 us per sub-step; 40 members: 29.6 against 25.8; 62: 36.0 against 38.7), and the two are bit-identical row by
+  // row (tests/test_gpu_parity.py), so the engine MEASURES: the first eight model steps of the first year run two warm-up
+  // steps, three timed steps of one form and three of the other between events on its own stream, and the faster form
+  // runs from then on.  The results do not depend on the choice.
+  static const int steps = tuning_int("GREB_DEBUG_NSTEPS", kNT); // -DGREB_TUNING builds only: a short stretch for counter passes
+  greb_engine::FormTrial* trial = nullptr;
+  int form = circ ? 2 : 1;
+  if (circ && !e->persistent_always) {
+    greb_engine::FormTrial& ft = e->circ_form[nrun];
+    if (ft.form == 0 && steps >= 16) {
+      trial = &ft;
+      for (hipEvent_t& ev : e->ev_trial) if (!ev) HIP_TRY(e, hipEventCreate(&ev));
+    } else if (ft.form) form = ft.form;
+  }
   // ... else one launch per sub-step
   const RowsTask *step_tasks = nullptr, *step_head = nullptr;
   int n_step_tasks = 0;
-  if (rows && !circ) {
+  if (rows && (form == 1 || trial)) {
     auto it = e->step_tasks.find(nrun);
     if (it == e->step_tasks.end()) {
       RowsTask* dev = nullptr; int n = 0;
@@ -285,13 +304,22 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
     step_tasks = it->second.dev; n_step_tasks = it->second.n; step_head = it->second.head;
   }
   HIP_TRY(e, launch_pack_tracers(e->state, e->Xa, e->np, nrun, e->stream));
-  static const int steps = tuning_int("GREB_DEBUG_NSTEPS", kNT); // -DGREB_TUNING builds only: a short stretch for counter passes
   for (int s = 0; s < steps; ++s) {
     const long long it = a.it0 + s;
     const int ityr = (int)((it - 1) % kNT) + 1;
     const size_t off = (size_t)(ityr - 1) * np;
     float *cur = e->Xa, *nxt = e->Xb;
-    if (circ) {
+    if (trial) { // steps 0-1 warm up, 2-4 one launch per sub-step, 5-7 one launch per call
+      if (s == 2 || s == 5 || s == 8) HIP_TRY(e, hipEventRecord(e->ev_trial[s == 2 ? 0 : (s == 5 ? 1 : 2)], e->stream));
+      if (s == 8) {
+        HIP_TRY(e, hipEventSynchronize(e->ev_trial[2]));
+        HIP_TRY(e, hipEventElapsedTime(&trial->ms_substep, e->ev_trial[0], e->ev_trial[1]));
+        HIP_TRY(e, hipEventElapsedTime(&trial->ms_call, e->ev_trial[1], e->ev_trial[2]));
+        form = trial->form = trial->ms_call <= trial->ms_substep ? 2 : 1;
+        trial = nullptr;
+      } else form = (s >= 2 && s < 5) ? 1 : 2;
+    }
+    if (form == 2) {
       HIP_TRY(e, launch_circulation_rows(e->Xa, e->Xb, e->W2, e->uclim + off, e->vclim + off, e->tabs, *circ, e->cus * 4, e->ny,
                                          a.nsub, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
       if (a.nsub & 1) cur = e->Xb;
@@ -481,6 +509,7 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
     e->step_rows_always = (flags & GREB_F_ROW_STRIPS) != 0;
     static const bool no_persistent = tuning_int("GREB_NO_PERSISTENT", 0) != 0; // -DGREB_TUNING builds only (A/B)
     e->persistent = e->step_rows && !no_persistent && !(flags & GREB_F_NO_PERSISTENT);
+    e->persistent_always = e->persistent && (flags & GREB_F_PERSISTENT) != 0;
     if (e->persistent) ledger_register(e);
   }
   return 0;
@@ -497,6 +526,7 @@ int greb_engine_destroy(greb_engine* e) {
   for (auto& kv : e->step_tasks) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (auto& kv : e->circ_orders) circ_rows_free_order(&kv.second);
   if (e->persistent) ledger_release(e);
+  for (hipEvent_t ev : e->ev_trial) if (ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < 2; ++i) {
     if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
     if (e->ev_free[i]) (void)hipEventDestroy(e->ev_free[i]);
@@ -614,6 +644,33 @@ int greb_engine_run(greb_engine* e, int years, const float* co2_ppm, float* mont
   e->it_scnr += (long long)years * kNT;
   if (yearly) HIP_TRY(e, hipMemcpy(yearly, e->yearly_dev, nm * years * 2 * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
+}
+
+const char* greb_engine_describe(greb_engine* e) {
+  static thread_local std::string s;
+  if (!e) { s = "{}"; return s.c_str(); }
+  char buf[256];
+  std::snprintf(buf, sizeof(buf), "{\"grid\": [%d, %d], \"members\": %d, \"arithmetic\": \"%s\", \"engine\": \"%s\"", e->nx, e->ny, e->nm,
+                e->strict ? "strict" : "fast", e->fused ? "fused member kernel" : (e->step_rows ? "row strips" : "latitude bands"));
+  s = buf;
+  if (e->persistent) {
+    std::snprintf(buf, sizeof(buf), ", \"wavefront_slots_granted\": %d, \"circulation\": [", e->slots_granted);
+    s += buf;
+    bool first = true;
+    for (const auto& kv : e->circ_orders) {
+      const auto ft = e->circ_form.find(kv.first);
+      const int form = e->persistent_always ? 2 : (ft == e->circ_form.end() ? 0 : ft->second.form);
+      std::snprintf(buf, sizeof(buf), "%s{\"members_run\": %d, \"tasks_of_one_launch_per_call\": %d, \"form\": \"%s\", \"trial_ms_per_3_steps\": [%.4f, %.4f]}",
+                    first ? "" : ", ", kv.first, kv.second.n,
+                    kv.second.n == 0 ? "one launch per sub-step (slots)" : (form == 2 ? "one launch per call" : (form == 1 ? "one launch per sub-step" : "undecided")),
+                    ft == e->circ_form.end() ? 0.f : ft->second.ms_substep, ft == e->circ_form.end() ? 0.f : ft->second.ms_call);
+      s += buf;
+      first = false;
+    }
+    s += "]";
+  }
+  s += "}";
+  return s.c_str();
 }
 
 int greb_engine_get_state(greb_engine* e, int member, float* state5) {

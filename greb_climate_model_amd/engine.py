@@ -55,7 +55,7 @@ EXPORTS = ["greb_params_default", "greb_engine_create", "greb_engine_flux_correc
            "greb_advection_batched", "greb_circulation_batched", "greb_diffusion_batched_dev",
            "greb_engine_point_physics", "greb_log_exp_switches", "greb_engine_set_experiment",
            "greb_ensemble_moments_dev", "greb_ensemble_quantiles_dev", "greb_engine_set_state", "greb_release_caches", "greb_diffusion_launch_order",
-           "greb_substep_launch_order", "greb_circulation_launch_plan"]
+           "greb_substep_launch_order", "greb_circulation_launch_plan", "greb_engine_describe"]
 
 
 def _check(rc: int, h=None):
@@ -87,7 +87,9 @@ class Engine:
 
     def __init__(self, inp: workload.Inputs, params: abi.GrebParams | None = None, n_members: int = 1,
                  overrides=None, device: int = 0, strict: bool = False, multilaunch: bool = False,
-                 row_strips: bool = False, persistent: bool = True):
+                 row_strips: bool = False, persistent: bool | None = None):
+        """persistent (384-wide grids): True = the circulation call as one launch (GREB_F_PERSISTENT), False = one launch per
+        sub-step (GREB_F_NO_PERSISTENT), None = the engine times both and keeps the faster."""
         L = lib()
         self.params = params or params_default()
         self.nx, self.ny, self.np, self.nm = inp.nx, inp.ny, inp.nx * inp.ny, n_members
@@ -101,7 +103,8 @@ class Engine:
         self.h = C.c_void_p()
         rc = L.greb_engine_create(C.byref(self.params), inp.nx, inp.ny, C.byref(fields), n_members, ov, device,
                                   (abi.F_STRICT if strict else 0) | (abi.F_MULTILAUNCH if multilaunch else 0) |
-                                 (abi.F_ROW_STRIPS if row_strips else 0) | (0 if persistent else abi.F_NO_PERSISTENT),
+                                 (abi.F_ROW_STRIPS if row_strips else 0) |
+                                  (0 if persistent is None else (abi.F_PERSISTENT if persistent else abi.F_NO_PERSISTENT)),
                                   C.byref(self.h))
         if rc != 0:
             msg = L.greb_engine_last_error(self.h).decode()
@@ -109,6 +112,12 @@ class Engine:
                 L.greb_engine_destroy(self.h)
                 self.h = None
             raise GrebError(rc, msg)
+
+    def describe(self) -> dict:
+        """greb_engine_describe: grid, members, arithmetic, which circulation form runs (and the trial's timings)."""
+        f = lib().greb_engine_describe
+        f.restype = C.c_char_p
+        return json.loads(f(self.h).decode())
 
     def close(self):
         if getattr(self, "h", None):

@@ -87,11 +87,14 @@ typedef struct greb_member_overrides {
                                 at every member count; this flag extends it to STRICT arithmetic, which otherwise keeps
                                 the band kernel (greb_kernels.hip: sweep_kernel<fused>).  The two are bit-identical in
                                 STRICT (tests/test_gpu_parity.py::test_row_strip_substep_equals_band_kernel_strict) */
-#define GREB_F_NO_PERSISTENT 8u /* 384-wide grids: one launch per circulation SUB-STEP (24 per model step) instead of
-                                   the default one launch per circulation CALL, whose strips hand their rows to each other
-                                   through memory flags and therefore need every strip of the launch resident at once
-                                   (asserted against the device's wavefront slots; engines created while another engine
-                                   of this process holds the slots of the device fall back to this form by themselves) */
+/* 384-wide grids, row strips: the circulation call (src/greb.f90:546-550: 24 sub-steps inside one call) runs either
+ * as one launch per SUB-STEP (greb_step_rows.hip) or as ONE launch per call (greb_circ_rows.hip), whose strips hand
+ * their rows to each other through memory flags and therefore need every strip of the launch resident at once (asserted
+ * against the device's wavefront slots; an engine created while other engines of the process hold the slots of its device
+ * takes one launch per sub-step by itself).  The two are bit-identical; which is faster depends on the member count, so
+ * by default the engine times both during the first eight model steps it integrates and keeps the faster. */
+#define GREB_F_NO_PERSISTENT 8u /* always one launch per sub-step */
+#define GREB_F_PERSISTENT 16u   /* one launch per call wherever it can be resident, without the trial */
 
 typedef struct greb_engine greb_engine;
 
@@ -110,6 +113,9 @@ int greb_engine_create(const greb_params* p, int nx, int ny, const greb_fields* 
  * yearly may be NULL, else [n_members][years][2] = {global-mean Tsurf, Tsurf(ipx,ipy)} in
  * deg C as printed at src/greb.f90:954. */
 int greb_engine_flux_correction(greb_engine* e, int years, float* yearly);
+
+/* What the engine is and which kernels it has settled on, as a JSON object (valid until the next call from this thread). */
+const char* greb_engine_describe(greb_engine* e);
 
 /* Scenario run (src/greb.f90:226-234 + time_loop :239-274): `years`*730 steps.
  *   co2_ppm : [n_members][years]   annual CO2, already padded (src/greb.f90:1053-1061)

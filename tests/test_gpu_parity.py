@@ -426,17 +426,29 @@ def test_one_launch_circulation_equals_one_launch_per_substep_fast(eng_mod, inpu
         for o in ov:
             o["kappa"] = max(o["kappa"], 7.4e5)  # (the 1 800-sweep rows are in the 5-member case; here: a short run)
     out = []
-    for persistent in (False, True):
+    # one launch per sub-step | one launch per call | the default: the engine times both in its first eight model steps
+    # (switching between them mid-year) and keeps the faster
+    for persistent in (False, True, None):
         e = eng_mod.Engine(inputs384, abi.default_params(ipx=380, ipy=152), n_members=members, overrides=ov, persistent=persistent)
         yf = e.flux_correction(1)
         mon, yr = e.run(1, 680.0)
         st = [e.state(m) for m in range(members)]
+        d = e.describe()
         e.close()
         out.append((mon, yr, yf, st))
+        forms = {c["members_run"]: c["form"] for c in d.get("circulation", [])}
+        print(f"members {members} persistent={persistent}: {d}")
+        if persistent is False:
+            assert not forms
+        else:
+            assert forms and all(f.startswith("one launch per") for f in forms.values()), d  # decided, every members_run
+            if persistent:
+                assert set(forms.values()) == {"one launch per call"}, d
     assert np.isfinite(out[1][0]).all()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
-    for a, b in zip(out[0][3], out[1][3]):
-        assert np.array_equal(a, b)
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1]) and np.array_equal(out[0][2], other[2])
+        for a, b in zip(out[0][3], other[3]):
+            assert np.array_equal(a, b)
 
 
 def test_row_strip_substep_with_experiment_switches(eng_mod, inputs384):
