@@ -36,6 +36,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--members", type=int, default=512, help="ensemble members per GPU")
+    ap.add_argument("--root-members", type=int, default=None,
+                    help="N > 1: members rank 0 integrates (default: --members).  Rank 0 also hosts the receive side of every "
+                         "gather; if the per-rank report shows it as the straggler, give it a smaller share")
     ap.add_argument("--strict", action="store_true", help="reference operation order (bit-exact stencils)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -111,7 +114,7 @@ def launch_ranks(args, argv):
     return rc
 
 
-def dry_launch(world, rank, members):
+def dry_launch(world, rank, members, root_members=None):
     """--dry-launch: rendezvous over gloo, report how the ensemble is dealt to the ranks and push a toy monthly record
     (each member's own CO2 level) through the timed run's gather path and its order check; no GPU call."""
     import torch
@@ -120,8 +123,11 @@ def dry_launch(world, rank, members):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    ids = ensemble.partition(world * members, world, rank)
-    levels = ensemble.co2_sweep(world * members)
+    R = members if root_members is None else root_members
+    total = R + (world - 1) * members
+    ids = ensemble.partition_root(members, R, world, rank)
+    levels = ensemble.co2_sweep(total)
+    t_start = time.perf_counter()
     mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "first": int(ids[0]), "count": int(len(ids)),
             "co2_first": float(levels[ids[0]])}
     parts, check = [mine], {"ranks_seen": 1, "backend": "none", **ensemble.gather_order_check(levels)}
@@ -129,15 +135,26 @@ def dry_launch(world, rank, members):
         parts = [None] * world
         dist.all_gather_object(parts, mine)
         g = ensemble.MonthlyGather(members, 1, (1, 1, 4), torch.float32, "cpu")
-        toy = torch.tensor(levels[ids], dtype=torch.float32).reshape(members, 1, 1, 1).expand(members, 1, 1, 4).contiguous()
+        toy = torch.zeros((members, 1, 1, 4), dtype=torch.float32)  # (rank 0's block is padded to the common size)
+        toy[: len(ids)] = torch.tensor(levels[ids], dtype=torch.float32).reshape(-1, 1, 1, 1)
         g.submit(0, toy)
+        t_wait = time.perf_counter()
         got = g.finish()
+        t_wait = time.perf_counter() - t_wait
         check = {"ranks_seen": ensemble.ranks_seen("cpu"), "backend": dist.get_backend()}
+        check["per_rank_s"] = ensemble.rank_report({"total": time.perf_counter() - t_start, "gather_wait": t_wait, "integrate": 0.0})
         if rank == 0:
-            check.update(ensemble.gather_order_check(got[:, 0].double().mean(dim=(1, 2, 3)).numpy(), block=members))
+            valid = gathered_valid(got[:, 0].double().mean(dim=(1, 2, 3)).numpy(), members, R)
+            check.update(ensemble.gather_order_check(valid, block=members if R == members else 0))
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": world, "members_per_gpu": members, "partition": parts, **check}))
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "members_per_gpu": members, "root_members": R, "members_total": total,
+                          "partition": parts, **check}))
+
+
+def gathered_valid(per_member, members, root_members):
+    """Rank 0's block of the gather buffer is padded to `members`; drop the padding (global member order is kept)."""
+    return np.concatenate([per_member[:root_members], per_member[members:]])
 
 
 def main():
@@ -153,7 +170,7 @@ def main():
               f"than the one asked for", file=sys.stderr)
         sys.exit(2)
     if args.dry_launch:
-        return dry_launch(world, rank, args.members)
+        return dry_launch(world, rank, args.members, args.root_members)
 
     import torch
     import torch.distributed as dist
@@ -171,28 +188,44 @@ def main():
             dist.init_process_group(backend)
 
     from greb_climate_model_amd import engine, ensemble, workload
+    variant_lib = None
     if os.environ.get("GREB_BENCH_LIB"):  # A/B of a variant library (tools/build_member_variant.sh); never set by the driver
-        engine._lib_path = os.path.abspath(os.environ["GREB_BENCH_LIB"])
+        variant_lib = engine._lib_path = os.path.abspath(os.environ["GREB_BENCH_LIB"])
     K, W, M = args.steps, args.warmup, args.members
     inp = workload.make_inputs()
     params = engine.params_default()
     params.ipx, params.ipy = 95, 38
 
-    # ---------------- ensemble: global member g = rank*M + i, CO2 swept over 280..1120 ppm
-    ids = ensemble.partition(world * M, world, rank)  # contiguous block of M members per rank
-    levels = ensemble.co2_sweep(world * M)[ids]
-    eng = engine.Engine(inp, params, n_members=M, device=local_rank, strict=args.strict)
+    # ---------------- ensemble: contiguous blocks of global members in rank order, CO2 swept over 280..1120 ppm
+    R = M if (args.root_members is None or world == 1) else args.root_members
+    if not 1 <= R <= M:
+        print(f"bench.py: --root-members {R} must be in 1..--members ({M})", file=sys.stderr)
+        sys.exit(2)
+    total_members = R + (world - 1) * M
+    ids = ensemble.partition_root(M, R, world, rank)  # M members per rank (rank 0: R)
+    levels = ensemble.co2_sweep(total_members)[ids]
+    my_m = len(ids)
+    eng = engine.Engine(inp, params, n_members=my_m, device=local_rank, strict=args.strict)
     eng.flux_correction(1)  # shared by all members (same physics): one member integrated, state broadcast
     np_ = eng.np
-    monthly = torch.empty((M, K, 12, 5, np_), dtype=torch.float32, device="cuda")
+    # (N > 1 writes each year into its own contiguous [M, 1, 12, 5, np] buffer below: no [M, K, ...] tensor there)
+    monthly = torch.empty((M, K, 12, 5, np_), dtype=torch.float32, device="cuda") if world == 1 else None
     gathered = None
+    times = {"integrate": 0.0, "gather_wait": 0.0}
 
-    def years_with_gather(n_years, bufs, g):
+    def years_with_gather(n_years, bufs, g, clock=None):
         """n_years model years, one engine call per year; year y's gather (RCCL over xGMI) overlaps year y+1."""
         for y in range(n_years):
-            eng.run(1, levels[:, None], monthly_dev_ptr=bufs[y].data_ptr())
+            t = time.perf_counter()
+            eng.run(1, levels[:, None], monthly_dev_ptr=bufs[y].data_ptr())  # (rank 0 with R < M fills the first R members)
+            if clock is not None:
+                clock["integrate"] += time.perf_counter() - t
             g.submit(y, bufs[y][:, 0])
-        return g.finish()
+        t = time.perf_counter()
+        out = g.finish()
+        if clock is not None:
+            clock["gather_wait"] += time.perf_counter() - t
+        return out
 
     if world == 1:
         if W > 0:
@@ -219,32 +252,39 @@ def main():
             dist.barrier()
 
     gather = ensemble.MonthlyGather(M, K, (12, 5, np_), torch.float32, "cuda") if world > 1 else None
-    year_bufs = [monthly[:, y] for y in range(K)]  # [M, 12, 5, np] views are not contiguous per year ...
-    if world > 1:  # ... so multi-GPU runs write each year into its own contiguous buffer
-        year_bufs = [torch.empty((M, 1, 12, 5, np_), dtype=torch.float32, device="cuda") for _ in range(K)]
+    year_bufs = None
+    if world > 1:  # each year in its own contiguous buffer (a [M, 12, 5, np] view of an [M, K, ...] tensor is not)
+        year_bufs = [torch.zeros((M, 1, 12, 5, np_), dtype=torch.float32, device="cuda") for _ in range(K)]
     barrier()
     t0 = time.perf_counter()
     if world == 1:
         eng.run(K, np.repeat(levels[:, None], K, 1), monthly_dev_ptr=monthly.data_ptr())
     else:
-        gathered = years_with_gather(K, year_bufs, gather)
+        gathered = years_with_gather(K, year_bufs, gather, times)
+    torch.cuda.synchronize()
+    times["total_before_barrier"] = time.perf_counter() - t0  # this rank's own work, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    value = world * M * K / dt
+        per_rank = ensemble.rank_report(times, device="cuda")
+    value = total_members * K / dt
 
     # N > 1: prove what the collective did -- how many ranks it connected, and that every member landed in its own
     # slot of rank 0's tensor (the CO2 sweep grows with the global member index, and so does last year's mean Tsurf)
     multi = None
     if world > 1:
         multi = {"ranks_seen": ensemble.ranks_seen("cuda"), "backend": dist.get_backend()}
+        multi["per_rank_s"] = per_rank  # integrate / gather_wait / total_before_barrier: per rank, min, max, rank of max
+        multi["root_members"] = R
         if rank == 0:
-            multi.update(ensemble.gather_order_check(gathered[:, -1, :, 0].double().mean(dim=(1, 2)).cpu().numpy(), block=M))
+            valid = gathered_valid(gathered[:, -1, :, 0].double().mean(dim=(1, 2)).cpu().numpy(), M, R)
+            multi.update(ensemble.gather_order_check(valid, block=M if R == M else 0))
     finite = bool(torch.isfinite(monthly if gathered is None else gathered).all().item())
-    tmean = float((monthly[:, -1, :, 0] if world == 1 else year_bufs[-1][:, 0, :, 0]).mean().item())
+    tmean = float((monthly[:, -1, :, 0] if world == 1 else year_bufs[-1][:my_m, 0, :, 0]).mean().item())
 
     extra = {}
     if rank == 0:
@@ -267,7 +307,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_g384:
         eng.close()  # the 384x192 ensemble wants the HBM (41 GB of per-member flux corrections at 64 members)
-        del monthly, year_bufs
+        del monthly
         torch.cuda.empty_cache()
         g384 = g384_object(torch, engine, ensemble, workload, local_rank, args.strict)
 
@@ -277,7 +317,7 @@ def main():
             "value": round(value, 2), "unit": "simulated-years/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * dt / K, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"96x48 GREB ensemble, {M} members/GPU x {world} GPU, CO2 sweep 280-1120 ppm, "
+            "config": {"workload": f"96x48 GREB ensemble, {M} members/GPU x {world} GPU" + (f" (rank 0: {R})" if R != M else "") + ", CO2 sweep 280-1120 ppm, "
                                    f"{K} scenario years after 1 flux-correction year, dt=12h, dt_crcl=0.5h",
                        "members_per_gpu": M, "arithmetic": "strict" if args.strict else "fast",
                        "gather": "rccl gather of monthly means to rank 0, one per year, overlapped with the next year" if world > 1 else "none (1 GPU)"},
@@ -286,6 +326,8 @@ def main():
             "device": engine.device_info(local_rank),
         }
         out.update(extra)
+        if variant_lib:  # NOT the product library: say so in the line itself
+            out["lib"] = variant_lib
         if multi is not None:
             out.update(multi)
         # the engine itself is not HBM-bound: its algorithmic arithmetic, 77 flop per point, tracer and
@@ -350,6 +392,11 @@ def after_idle(torch, engine, params, nx, ny, batch, strict, bufs, launches=60):
             "mean_ms_launches_2_to_9": round(float(np.mean(ms[1:9])), 4), "mean_ms_launches_21_to_60": round(float(np.mean(ms[20:])), 4)}
 
 
+# the committed counter records the line quotes (tools/verify_round.sh profiles writes them, each with the hash of the
+# kernel code it was collected on; tests/test_profiles_cpu.py fails when the built library has other code)
+TRAFFIC_FILE, G384_DIF_FILE, G384_STEP_FILE = "r04_roofline_traffic.json", "r04_g384_diffusion_pmc.json", "r04_g384_substep_pmc.json"
+
+
 def pmc_record(name):
     """Counter figures of a kernel from the committed rocprofv3 --pmc passes (profiles/<name>.json, written by
     tools/pmc_rows_summary.py / tools/verify_round.sh: rocprofv3 cannot wrap itself around this process)."""
@@ -371,6 +418,7 @@ def sweep_stats(ms, algo):
 
 
 def roofline_diffusion(torch, engine, params, batch, strict, sweeps=20):
+    from greb_climate_model_amd import codesha
     """Standalone batched diffusion sweep (src/greb.f90:556-723) timed with HIP events on the
     stream it is launched on.  Algorithmic bytes = 12 B/point/field-sweep (SURVEY.md 8d):
     read T1, read wz, write dX.  batch*3*18 KB >= 0.9 GB so the 256 MB Infinity Cache cannot
@@ -398,8 +446,10 @@ def roofline_diffusion(torch, engine, params, batch, strict, sweeps=20):
     out.update(sweep_stats(ms, algo))
     # HBM traffic per launch from the committed PMC run: FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request,
     # MI355X_MICROARCH.md) + WRITE_SIZE, scaled to this batch
-    tj = pmc_record("r03_roofline_traffic.json")
+    tj = pmc_record(TRAFFIC_FILE)
     out["traffic"] = int(tj["traffic_bytes_per_launch"] * batch / tj["batch"]) if tj else None
+    # ... and which machine code that run profiled: the hash in the record against the kernel in the library loaded here
+    out["traffic_source"] = codesha.source_check(tj, "profiles/" + TRAFFIC_FILE, engine._lib_path)
     out.update({"batch": batch, "timing": f"{sweeps} launches, each between two HIP events, after >= 80 ms of the same launch back to back",
                 "after_1s_idle": cold, "measured_copy_GBps": round(copy_gbs, 1),
                 "frac_of_measured_copy": round(out["achieved"] / copy_gbs, 4)})
@@ -409,8 +459,9 @@ def roofline_diffusion(torch, engine, params, batch, strict, sweeps=20):
 def g384_object(torch, engine, ensemble, workload, device, strict):
     """BASELINE configs 3 and 5 at their own grid, 384x192 (inputs: the synthetic workload bilinearly refined,
     SURVEY.md C.1), one scenario year each after one flux-correction year:
-      config3   1 member (any-grid multi-launch engine: 24 band sub-step launches + 1 point-physics launch per model
-                step); bound by the latency of the longest Jacobi chain of a launch (row 2: 225 dependent sweeps)
+      config3   1 member (any-grid engine on row strips: per model step ONE launch for the 24 sub-steps of the
+                circulation call, greb_circ_rows.hip, + 1 point-physics launch -- or 24 + 1 launches, whichever the
+                engine's own trial found faster); bound by the longest dependent chain (row 2: 225 + 7 sweeps per sub-step)
       config5   64 perturbed-physics members (da_ice, a_no_ice, a_cloud, kappa +-10 %, ensemble.perturbed_physics), as
                 drawn, and without the members whose kappa < 7.27e5 gives the two polar rows 1 800 dependent diffusion
                 sweeps per call instead of none (the reference's integer dtdff2 is 1 instead of 0 there,
@@ -419,6 +470,7 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
                 96x48 roofline line (884 736 B per field, batch 1 024 = 0.9 GB per launch): every row is sub-cycled
                 here, so the kernel is bound by the chain rows' arithmetic, not by HBM"""
     import gc
+    from greb_climate_model_amd import codesha
     nx, ny = 384, 192
     inp = workload.make_inputs(nx, ny)
     p = engine.params_default(); p.ipx, p.ipy = 380, 152
@@ -434,14 +486,25 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         ok = bool(torch.isfinite(buf).all().item())
+        form = [c for c in e.describe().get("circulation", []) if c["members_run"] == n_members]
         e.close(); del buf
         gc.collect(); torch.cuda.empty_cache()
-        return n_members / dt, dt, ok
+        return n_members / dt, dt, ok, (form[0] if form else None)
 
-    r, dt, ok = year_rate(1, None)
-    out["config3_single_member"] = {"years_per_s": round(r, 3), "us_per_substep_launch": round(dt / (730 * 25) * 1e6, 2),
-                                    "finite": ok, "bound": "latency of one wavefront's 232-sweep polar row per launch: 14.9 of the ~18.5 us "
-                                                           "(profiles/r03_g384_substep_stamps.txt: 138-147 cycles per dependent sweep, one instruction per 4.0 cycles)"}
+    def form_fields(form, dt):
+        """us per circulation sub-step of the timed year (its point-physics launch included), and which launch form ran"""
+        d = {"us_per_substep": round(dt / (730 * 24) * 1e6, 2)}
+        if form:
+            d.update({"circulation_form": form["form"], "tasks_per_launch": form["tasks_of_one_launch_per_call"],
+                      "trial_ms_per_3_steps_substep_vs_call": form["trial_ms_per_3_steps"]})
+        return d
+
+    r, dt, ok, form = year_rate(1, None)
+    chain_us = 232 * 140 / 2.4e3  # 225 + 7 dependent sweeps of ~140 cycles at ~2.4 GHz (profiles/r03_chain_rate.txt)
+    out["config3_single_member"] = {"years_per_s": round(r, 3), "finite": ok, **form_fields(form, dt),
+                                    "bound": f"latency of one wavefront's 232-sweep polar row: ~{chain_us:.1f} us of the {dt / (730 * 24) * 1e6:.1f} us per sub-step "
+                                             "(138-147 cycles per dependent sweep, one instruction per 4.0 cycles: profiles/r03_chain_rate.txt); in the one-launch form "
+                                             "that row stays in registers for the whole call (profiles/r04_circ_timeline.txt)"}
     ov = ensemble.perturbed_physics(64, p)
     as_dicts = lambda rows: [dict(zip(ensemble.PERTURBED, map(float, row))) for row in rows]
     slow = ov[:, 3] < 7.27e5
@@ -466,11 +529,12 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
                                  "bound": "latency of the 1800-sweep polar chains of the kappa < 7.27e5 members (their own engine, "
                                           "run beside the engine of the other members)"}
     keep = ov[~slow]
-    r, dt, ok = year_rate(len(keep), as_dicts(keep))
-    out["config5_without_those_members"] = {"members": int(len(keep)), "member_years_per_s": round(r, 2), "finite": ok,
-                                            "bound": "instruction issue of the row-strip sub-step (greb_step_rows.hip): one instruction per SIMD every 4 cycles, 14 M vector "
-                                                     "instructions per launch = 22.7 us on 1 024 SIMDs perfectly balanced; two wavefronts per SIMD at 187 VGPRs, "
-                                                     "one round of <= 2 048 strips (tools/step_timeline.py: kernel 33-34 us, the rest is the point-physics launch and launch gaps)"}
+    r, dt, ok, form = year_rate(len(keep), as_dicts(keep))
+    pj = pmc_record(G384_STEP_FILE)
+    floor = f"{pj['valu_insts_per_substep'] / 1e6:.1f} M vector instructions per sub-step = {pj['issue_floor_us']:.1f} us on 1 024 perfectly balanced SIMDs ({pj['source']})" if pj else "no committed counter pass found"
+    out["config5_without_those_members"] = {"members": int(len(keep)), "member_years_per_s": round(r, 2), "finite": ok, **form_fields(form, dt),
+                                            "bound": "instruction issue of the row strips: one vector instruction per SIMD every 4 cycles, shared by the two wavefronts "
+                                                     f"a SIMD holds (177-200 VGPRs, 19.5 KB of LDS each); {floor}"}
     # standalone diffusion sweep, HIP events on the launching stream
     batch = 1024
     n = batch * nx * ny
@@ -481,13 +545,14 @@ def g384_object(torch, engine, ensemble, workload, device, strict):
     ms = timed_sweeps(torch, engine, p, nx, ny, batch, strict, (T1, wz, dX), 20)
     d = {"kernel": "dif_rows_kernel<strict>" if strict else "dif_rows_kernel<fast> (wavefront-sized row strips, greb_rows.hip)", "batch": batch}
     d.update(sweep_stats(ms, 12.0 * n))
-    pj = pmc_record("r03_g384_diffusion_pmc.json")
+    pj = pmc_record(G384_DIF_FILE)
+    d["traffic_source"] = codesha.source_check(pj, "profiles/" + G384_DIF_FILE, engine._lib_path)
     if pj:  # the bound as the counters of the committed passes give it (same kernel, same batch)
         d["traffic"] = int(pj["traffic_bytes_per_launch"])
         d["bound"] = (f"hbm: HBM-side traffic {pj['traffic_bytes_per_launch'] / (12.0 * n):.3f} x the algorithmic bytes, "
                       f"{pj['waves_per_simd']:.1f} wavefronts resident per SIMD, VALU active {pj['valu_active_pct']:.0f} % of the SIMD-cycles "
                       f"({pj['valu_insts_per_field']:.0f} vector instructions per field), {pj['wave_cycles_parked_pct']:.0f} % of the wave-cycles "
-                      f"parked at s_waitcnt (profiles/r03_g384_diffusion_pmc.txt)")
+                      f"parked at s_waitcnt (profiles/{G384_DIF_FILE.replace('.json', '.txt')})")
     else:
         d["traffic"] = None
         d["bound"] = "hbm (no committed counter pass found)"

@@ -72,6 +72,45 @@ def build_lib(force: bool = False, verbose: bool = False, tuning: bool = False) 
     return lib
 
 
+LIB_ASAN = os.path.join(PKG, "libgreb_hip_asan.so")
+
+
+def build_lib_asan(verbose: bool = False) -> str:
+    """The library with HOST-side AddressSanitizer + UBSan (-fno-gpu-sanitize: device code as in the release build; GPU
+    sanitizers are not available on this pool and nothing here runs on a GPU): for tests/test_sanitizers_cpu.py, which
+    drives the host-only entry points (launch orders, launch plan, argument checks) through it.  Never loaded by the
+    product; stays in the build container (.gpurunignore)."""
+    from concurrent.futures import ThreadPoolExecutor
+    if os.path.exists(LIB_ASAN):
+        t = os.path.getmtime(LIB_ASAN)
+        if not (any(os.path.getmtime(d) > t for s in SOURCES for d in _deps(s)) or os.path.getmtime(__file__) > t):
+            return LIB_ASAN
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-shared-libsan", "-g"]
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + san
+
+    def one(src):
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + "_asan.o")
+        cmd = [hipcc(), *flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC, capture_output=not verbose)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, SOURCES))
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *san, "-o", LIB_ASAN, *objs], check=True, cwd=CSRC,
+                   capture_output=not verbose)
+    return LIB_ASAN
+
+
+def asan_runtime() -> str | None:
+    """clang's shared ASan runtime, to be LD_PRELOADed into an uninstrumented python that loads LIB_ASAN."""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return hits[-1] if hits else None
+
+
 def build_host(verbose: bool = False) -> str | None:
     """The thin Fortran hosts over iso_c_binding: greb_host (src/greb.f90's shell) and greb_host_original (the
     upstream variant's shell with the log_exp experiments) -> greb_climate_model_amd/.  Returns greb_host's

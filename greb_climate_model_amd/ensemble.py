@@ -108,6 +108,35 @@ def partition(n_members: int, world: int, rank: int) -> np.ndarray:
     return np.arange(start, start + base + (1 if rank < rem else 0))
 
 
+def partition_root(members: int, root_members: int, world: int, rank: int) -> np.ndarray:
+    """Global member ids owned by `rank` when rank 0 -- which also hosts the receive side of every gather -- carries
+    `root_members` members and every other rank `members`: contiguous blocks in rank order."""
+    if rank == 0:
+        return np.arange(0, root_members)
+    start = root_members + (rank - 1) * members
+    return np.arange(start, start + members)
+
+
+def rank_report(values, group=None, device="cpu") -> dict:
+    """Every rank's timings on rank 0: `values` = {name: seconds} of this rank -> {name: {"per_rank": [...], "min": ,
+    "max": , "rank_of_max": }} (all-gather of one small tensor over the run's own backend).  A straggler -- rank 0, if
+    RCCL's receive kernels take compute units from its integration -- shows here, where the max-over-ranks `dt` of the
+    benchmark contract cannot show it."""
+    import torch
+    import torch.distributed as dist
+    names = sorted(values)
+    mine = torch.tensor([float(values[k]) for k in names], dtype=torch.float64, device=device)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        allv = torch.stack(parts).cpu().numpy()
+    else:
+        allv = mine.cpu().numpy()[None]
+    return {k: {"per_rank": [round(float(x), 6) for x in allv[:, i]], "min": round(float(allv[:, i].min()), 6),
+                "max": round(float(allv[:, i].max()), 6), "rank_of_max": int(allv[:, i].argmax())} for i, k in enumerate(names)}
+
+
 def gather_monthly(local, n_members: int, group=None):
     """Gather per-rank monthly means [m_local, ...] to rank 0 -> [n_members, ...] (None elsewhere).
     Ragged member counts are padded to the largest block for the collective and trimmed after."""

@@ -35,6 +35,26 @@ def test_dry_launch_two_ranks_partition():
     # the toy record went through the timed run's gather path: both ranks seen, every member in its own slot
     assert out["ranks_seen"] == 2 and out["backend"] == "gloo"
     assert out["gather_verified"] is True and out["inversions"] == 0 and out["members_checked"] == 12
+    # every rank's own timings reach the line (a straggling rank 0 must show the first time)
+    pr = out["per_rank_s"]
+    assert set(pr) == {"total", "gather_wait", "integrate"}
+    for k, v in pr.items():
+        assert len(v["per_rank"]) == 2 and v["min"] <= v["max"] and v["rank_of_max"] in (0, 1), (k, v)
+        assert v["max"] == max(v["per_rank"]) and v["per_rank"][v["rank_of_max"]] == v["max"]
+    assert out["root_members"] == 6 and out["members_total"] == 12
+
+
+def test_dry_launch_root_rank_with_a_smaller_share():
+    """--root-members: rank 0 (which also hosts the receive side of every gather) integrates fewer members; the blocks
+    stay contiguous in rank order and the gathered members -- rank 0's padded slots dropped -- are in global order."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--members", "6", "--root-members", "2", "--dry-launch"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = _json_line(r.stdout)
+    assert [(p["first"], p["count"]) for p in out["partition"]] == [(0, 2), (2, 6), (8, 6)]
+    assert out["members_total"] == 14 and out["root_members"] == 2
+    assert out["gather_verified"] is True and out["members_checked"] == 14 and out["inversions"] == 0
+    assert len(out["per_rank_s"]["total"]["per_rank"]) == 3
 
 
 def test_gather_order_check_finds_a_misplaced_block():

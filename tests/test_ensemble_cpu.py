@@ -101,3 +101,11 @@ def test_monthly_gather_pipeline_world2():
     for p in procs: p.join(120)
     assert all(p.exitcode == 0 for p in procs)
     assert q.get(timeout=5) is True
+
+
+def test_partition_root_blocks():
+    from greb_climate_model_amd import ensemble
+    blocks = [ensemble.partition_root(8, 3, 4, r) for r in range(4)]
+    assert [len(b) for b in blocks] == [3, 8, 8, 8]
+    assert np.array_equal(np.concatenate(blocks), np.arange(27))
+    assert np.array_equal(ensemble.partition_root(8, 8, 4, 2), ensemble.partition(32, 4, 2))

@@ -3,6 +3,8 @@
 means and the figures derived from them by the rules of MI355X_MICROARCH.md (FETCH_SIZE x 2 on gfx950; SQ_* wave
 counters in quad-cycles; GRBM_GUI_ACTIVE summed over the 8 XCDs)."""
 import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from greb_climate_model_amd import build, codesha
 
 d = sys.argv[1]
 json_out = sys.argv[2] if len(sys.argv) > 2 else None  # record of the FAST row-strip kernel for bench.py's bound string
@@ -20,6 +22,7 @@ if os.path.exists(st):
         dur[r["Name"]] = (float(r["AverageNs"]) * 1e-3, float(r["MinNs"]) * 1e-3, float(r["MaxNs"]) * 1e-3, int(r["Calls"]))
 NF = int(os.environ.get("FIELDS", 1024))  # fields per launch (tools/prof_step.sh: 2 per member)
 ALGO = 12.0 * NF * 384 * 192
+best_step = (0.0, None)
 for k in sorted(cnt):
     if "greb" not in k:
         continue
@@ -64,5 +67,25 @@ for k in sorted(cnt):
                "waves_per_simd": round(c["SQ_WAVE_CYCLES"] * 4 / cyc / 1024, 2),
                "wave_cycles_issuing_pct": round(100 * c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 1),
                "wave_cycles_issue_stalled_pct": round(100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 1),
-               "wave_cycles_parked_pct": round(100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 1)}
+               "wave_cycles_parked_pct": round(100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 1),
+               "code": codesha.record(build.LIB, "dif_rows_kernelILb0E")}
         json.dump(rec, open(json_out, "w"), indent=1)
+    # the engine's circulation kernels at 384x192 (tools/prof_step.sh: FIELDS = 2 x members): the issue floor bench.py quotes
+    step_json = os.environ.get("STEP_JSON")
+    sub = "circ_rows_kernel<false" in k or "step_rows_kernel<false" in k
+    if step_json and sub and "SQ_INSTS_VALU" in c and "SQ_BUSY_CYCLES" in c:
+        one_call = "circ_rows_kernel" in k
+        nsub = 24 if one_call else 1  # a circ_rows_kernel launch is a whole circulation call
+        cyc = c["SQ_BUSY_CYCLES"] / 32
+        rec = {"kernel": "greb::circ_rows_kernel<false>" if one_call else "greb::step_rows_kernel<false>", "fields": NF,
+               "source": f"profiles/r04_g384_substep_pmc.txt: rocprofv3 --pmc passes (each on its own), tools/prof_step.sh",
+               "valu_insts_per_substep": round(c["SQ_INSTS_VALU"] / nsub),
+               "issue_floor_us": round(c["SQ_INSTS_VALU"] / nsub * 4 / 1024 / 2.4e3, 1),  # one instruction per SIMD per 4 cycles, 1 024 SIMDs, ~2.4 GHz
+               "valu_active_pct": round(100 * c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc), 1) if "SQ_ACTIVE_INST_VALU" in c else None,
+               "waves_per_simd": round(c["SQ_WAVE_CYCLES"] * 4 / cyc / 1024, 2) if "SQ_WAVE_CYCLES" in c else None,
+               "code": codesha.record(build.LIB, "circ_rows_kernelILb0E" if one_call else "step_rows_kernelILb0E")}
+        weight = len(cnt[k]["SQ_BUSY_CYCLES"]) * c["SQ_BUSY_CYCLES"]  # the form the engine settled on is the one that ran the year
+        if weight > best_step[0]:
+            best_step = (weight, rec)
+if best_step[1] is not None:
+    json.dump(best_step[1], open(os.environ["STEP_JSON"], "w"), indent=1)

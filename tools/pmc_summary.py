@@ -71,7 +71,9 @@ def derive(sq, lds, stats):
 
 def traffic_json(fetch, write):
     """profiles/rNN_roofline_traffic.json: HBM-side bytes per launch of the 96x48 roofline kernel (bench.py reads it)."""
-    import json
+    import json, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from greb_climate_model_amd import build, codesha
     key = "diffusion_stream_kernel<false"
     vals = {}
     for f, name in ((fetch, "FETCH_SIZE"), (write, "WRITE_SIZE")):
@@ -86,7 +88,10 @@ def traffic_json(fetch, write):
                                 "(MI355X_MICROARCH.md, HBM section)",
                       "batch": 16384, "fetch_size_kb_per_launch": round(fk), "write_size_kb_per_launch": round(wk),
                       "gfx950_fetch_correction": 2.0, "traffic_bytes_per_launch": round((2 * fk + wk) * 1024),
-                      "algorithmic_bytes_per_launch": 12 * 16384 * 96 * 48}, indent=1))
+                      "algorithmic_bytes_per_launch": 12 * 16384 * 96 * 48,
+                      # which machine code the passes ran on: the library of THIS tree (the passes and this summary belong
+                      # to one tools/verify_round.sh run); bench.py and tests/test_profiles_cpu.py compare it with theirs
+                      "code": codesha.record(build.LIB, "diffusion_stream_kernelILb0ELi96ELi48E")}, indent=1))
 
 
 if __name__ == "__main__":
