@@ -757,9 +757,11 @@ namespace {
 // a new buffer; the synchronous copy completes before the call that made it launches anything) -- and freed only by
 // greb_release_caches(), which waits for the device first.
 struct TabCache {
-  struct Entry { int device; RowTables* dev; RowTables host; };
+  struct Entry { int device; RowTables* dev; RowTables host; unsigned long long used; };
   std::mutex mu;
   std::vector<Entry> entries;
+  unsigned long long clock = 0;
+  static constexpr size_t kMax = 32; // a long-lived host that sweeps kappa: the least recently used table is retired
 } g_tab_cache;
 } // namespace
 
@@ -803,10 +805,20 @@ int greb_diffusion_batched_dev(const greb_params* p, int nx, int ny, int batch, 
   RowTables* tab_dev = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_tab_cache.mu);
-    for (const TabCache::Entry& ce : g_tab_cache.entries)
-      if (ce.device == dev && std::memcmp(&t, &ce.host, sizeof(t)) == 0) { tab_dev = ce.dev; break; }
+    for (TabCache::Entry& ce : g_tab_cache.entries)
+      if (ce.device == dev && std::memcmp(&t, &ce.host, sizeof(t)) == 0) { tab_dev = ce.dev; ce.used = ++g_tab_cache.clock; break; }
+    if (!tab_dev && g_tab_cache.entries.size() >= TabCache::kMax) { // (once the device is idle: a sweep in flight may read it)
+      size_t lru = g_tab_cache.entries.size();
+      for (size_t i = 0; i < g_tab_cache.entries.size(); ++i)
+        if (g_tab_cache.entries[i].device == dev && (lru == g_tab_cache.entries.size() || g_tab_cache.entries[i].used < g_tab_cache.entries[lru].used)) lru = i;
+      if (lru < g_tab_cache.entries.size()) {
+        HIP_TRY0(hipDeviceSynchronize());
+        (void)hipFree(g_tab_cache.entries[lru].dev);
+        g_tab_cache.entries.erase(g_tab_cache.entries.begin() + (long)lru);
+      }
+    }
     if (!tab_dev) {
-      TabCache::Entry ce{dev, nullptr, t};
+      TabCache::Entry ce{dev, nullptr, t, ++g_tab_cache.clock};
       HIP_TRY0(dev_alloc(&ce.dev, 1));
       hipError_t he = hipMemcpy(ce.dev, &t, sizeof(t), hipMemcpyHostToDevice);
       if (he != hipSuccess) { (void)hipFree(ce.dev); HIP_TRY0(he); }

@@ -322,9 +322,12 @@ struct TaskTable {
   int time2[kMaxNy];
   RowsTask* dev;
   int n;
+  unsigned long long used; // when it was last asked for (g_rows_clock)
 };
 std::mutex g_rows_mu;
 std::vector<TaskTable> g_rows_tables;
+unsigned long long g_rows_clock = 0;
+constexpr size_t kRowsTablesMax = 32; // a long-lived host that sweeps kappa or batch: the least recently used table goes
 } // namespace
 
 void rows_release_cache() {
@@ -342,12 +345,23 @@ static hipError_t rows_task_table(const RowTables& t, int ny, int batch, const R
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> lock(g_rows_mu);
-  for (const TaskTable& c : g_rows_tables)
+  for (TaskTable& c : g_rows_tables)
     if (c.device == device && c.ny == ny && c.batch == batch && std::memcmp(&c.tu, &tu, sizeof(tu)) == 0 &&
         std::memcmp(c.time2, t.dif_time2, sizeof(int) * ny) == 0) {
+      c.used = ++g_rows_clock;
       *dev = c.dev; *n = c.n;
       return hipSuccess;
     }
+  if (g_rows_tables.size() >= kRowsTablesMax) { // retire this device's least recently used table -- once the device is idle:
+    size_t lru = g_rows_tables.size();           // a sweep in flight on any stream may still be reading it
+    for (size_t i = 0; i < g_rows_tables.size(); ++i)
+      if (g_rows_tables[i].device == device && (lru == g_rows_tables.size() || g_rows_tables[i].used < g_rows_tables[lru].used)) lru = i;
+    if (lru < g_rows_tables.size()) {
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+      (void)hipFree(g_rows_tables[lru].dev);
+      g_rows_tables.erase(g_rows_tables.begin() + (long)lru);
+    }
+  }
   std::vector<RowsTask> tasks;
   rows_tasks(t, ny, batch, tu, tasks);
   TaskTable c{};
@@ -358,6 +372,7 @@ static hipError_t rows_task_table(const RowTables& t, int ny, int batch, const R
     (void)hipFree(c.dev);
     return e;
   }
+  c.used = ++g_rows_clock;
   g_rows_tables.push_back(c);
   *dev = c.dev; *n = c.n;
   return hipSuccess;

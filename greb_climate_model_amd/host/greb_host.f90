@@ -33,7 +33,7 @@
 !                        ensemble, process proc_id (0-based) of n_procs integrates its contiguous block of members --
 !                        block sizes differ by at most one, the rule of greb_climate_model_amd/ensemble.py:partition --
 !                        and writes only their <output_file>_<ens_id> files.  Also settable from the command line, so
-!                        that all processes share one namelist file:   greb_host <namelist> <proc_id> <n_procs> [plan]
+!                        that all processes share one namelist file:   greb_host <namelist> <proc_id> <n_procs> [plan]   (or: greb_host <namelist> plan)
 !                        (`plan` prints the block and stops before any input is read or any GPU is touched).  With
 !                        &ENGINE_PAR device unset, process proc_id uses GPU proc_id.  tools/launch_ensemble.py starts them.
 ! The interface module is host/greb_c_api.f90.
@@ -148,6 +148,9 @@ program greb_host
   end if
   if (nargs >= 4) then
      call get_command_argument(4, arg)
+     plan_only = trim(arg) == 'plan'
+  else if (nargs == 2) then  ! greb_host <namelist> plan: the block from the namelist's own n_procs / proc_id
+     call get_command_argument(2, arg)
      plan_only = trim(arg) == 'plan'
   end if
   if (n_procs < 1 .or. proc_id < 0 .or. proc_id >= n_procs) then

@@ -564,6 +564,28 @@ def test_config5_two_engines_beside_each_other_vs_reference(eng_mod, inputs384):
     assert np.array_equal(mon1, mon) and np.array_equal(yf1, yf) and np.array_equal(yr1, yr)
 
 
+def test_table_caches_are_bounded_and_stay_correct(eng_mod, params, inputs, inputs384, oracle_lib):
+    """A long-lived host that sweeps kappa: the device copies of row tables and launch orders behind the batched entry
+    points are LRU caches of 32 entries (an entry is retired only once the device is idle).  Forty diffusivities through
+    both grids, then the first again: bit-identical to its first answer and to the oracle."""
+    from greb_climate_model_amd import abi
+    f = np.float32
+    X96, W96 = inputs.tclim[0][None], np.full((1, 48, 96), f(0.7))
+    X384, W384 = inputs384.tclim[0][None], np.full((1, 192, 384), f(0.7))
+    first = None
+    for i in list(range(40)) + [0]:
+        p = abi.default_params(ipx=95, ipy=38)
+        p.kappa = f(8e5) * (f(1) + f(0.004) * f(i))
+        a = eng_mod.diffusion(X96, W96, p, strict=True)
+        b = eng_mod.diffusion(X384, W384, p, strict=True)
+        if first is None:
+            first = (a.copy(), b.copy())
+            o = oracle_lib.Oracle(inputs, p)
+            assert np.array_equal(a[0], o.diffusion(X96[0], W96[0]))
+            o.close()
+    assert np.array_equal(a, first[0]) and np.array_equal(b, first[1])
+
+
 # ------------------------------------------------------------------------------------ error behaviour
 def test_bad_arguments_are_errors_with_messages(eng_mod, params, inputs):
     """Nothing throws or exits across the ABI: bad shapes / indices / call arguments come back as GREB_E_INVALID

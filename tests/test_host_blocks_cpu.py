@@ -61,6 +61,26 @@ def test_ids_and_namelist_keys(tmp_path, host):
     assert bad.returncode != 0 and "proc_id" in bad.stdout + bad.stderr
 
 
+def test_block_from_the_namelist_alone(tmp_path, host):
+    """&ENSEMBLE_PAR n_procs / proc_id with NO ids on the command line (`greb_host <namelist> plan`): the same blocks as the
+    four-argument form, and the same error for an id outside the range."""
+    from greb_climate_model_amd import ensemble
+    for n_total, n_procs in ((11, 4), (8, 2)):
+        seen = []
+        for r in range(n_procs):
+            (tmp_path / "namelist").write_text(NML.format(n=n_total, extra=f"n_procs = {n_procs}\nproc_id = {r}\n"))
+            out = subprocess.run([host, "namelist", "plan"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+            assert out.returncode == 0, out.stdout + out.stderr
+            mine = [int(m.group(1)) for m in re.finditer(r"% member (\d+) ens_id", out.stdout)]
+            assert mine == list(ensemble.partition(n_total, n_procs, r) + 1), (r, mine)
+            assert f"process {r} of {n_procs}" in out.stdout and f"on device {r}" in out.stdout
+            seen += mine
+        assert seen == list(range(1, n_total + 1))
+    (tmp_path / "namelist").write_text(NML.format(n=4, extra="n_procs = 2\nproc_id = 2\n"))
+    bad = subprocess.run([host, "namelist", "plan"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "proc_id" in bad.stdout + bad.stderr
+
+
 def test_launcher_plan(tmp_path, host):
     (tmp_path / "namelist").write_text(NML.format(n=10, extra=""))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "launch_ensemble.py"), "--procs", "3", "--plan"],

@@ -18,7 +18,7 @@ if M > 1:
 kappa = np.array([r["kappa"] for r in ov], np.float32) if ov else None
 field, k0, k1 = engine.substep_launch_order(p, 384, 192, M, kappa)
 n = len(field)
-e = engine.Engine(inp, p, n_members=M, overrides=ov)
+e = engine.Engine(inp, p, n_members=M, overrides=ov, persistent=False)  # (the per-sub-step kernel is what this tool looks at)
 buf = torch.empty((M, 1, 12, 5, e.np), dtype=torch.float32, device="cuda")
 L.greb_tuning_step_timeline.argtypes = [C.c_void_p, C.c_int]
 assert L.greb_tuning_step_timeline(None, n) == 0
@@ -57,6 +57,8 @@ for i in range(n): pairs.setdefault(key[i], []).append(i)
 both = [v for v in pairs.values() if len(v) == 2]
 d = np.array([abs(v[0] - v[1]) for v in both])
 vals, c = np.unique(d, return_counts=True)
+n_simd = 4 * int(engine.device_info(0)["cus"])
+print(f"PREMISE tasks i and i + {n_simd} share a SIMD: {int((d == n_simd).sum())} of {len(both)} SIMDs that hold two tasks")
 print("index distance of the two tasks that share a SIMD (distance: count):", " ".join(f"{a}:{b}" for a, b in sorted(zip(vals, c), key=lambda x: -x[1])[:12]))
 capk = {i for i in range(n) if not stream[i]}
 print("SIMDs holding two polar strips:", sum(1 for v in both if v[0] in capk and v[1] in capk), " one polar + one streaming:", sum(1 for v in both if (v[0] in capk) != (v[1] in capk)), " two streaming:", sum(1 for v in both if v[0] not in capk and v[1] not in capk))
