@@ -48,6 +48,7 @@ struct CircArgs {
   unsigned* ctrl;
   unsigned epoch0;         // what every flag reads when the launch starts
   unsigned spin_ticks;
+  int n_tasks;
   int ny, nsub, calm_odd;  // calm_odd: the vapour fields see zero wind (greb.original.model.f90:560-564)
   int chains_first;        // who issues first where a chain and a streaming strip share a SIMD
   int chain_head, chain_tail; // sweeps of a chain task's diffusion chain before it publishes the previous sub-step / after it polls
@@ -56,6 +57,16 @@ struct CircArgs {
 };
 
 typedef __attribute__((address_space(4))) CircTask ctask;
+
+// A workgroup is FOUR wavefronts = four tasks, one per SIMD of the compute unit it lands on (the wavefronts of a workgroup
+// are dealt to the SIMDs in turn): which tasks share a SIMD -- i and i + n_simd, the rule circ_rows_tasks pairs by -- then
+// follows from how workgroups are dealt to compute units and no longer from where single-wavefront workgroups happen
+// to land (observed: of 998 such workgroups on 1 024 idle SIMDs, 54 SIMDs got two and 80 none).  The four share nothing:
+// no barrier, each its own 19.5 KB of the workgroup's LDS.
+constexpr int kTasksPerGroup = 4;
+__device__ __forceinline__ int task_index() {
+  return (int)blockIdx.x * kTasksPerGroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
 
 __device__ __forceinline__ void flag_store(unsigned* p, unsigned v) {
   asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
@@ -70,7 +81,7 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned value, unsigned
 
 __device__ __forceinline__ void give_up(const CircArgs& a, int s, unsigned seen, unsigned want, unsigned lane) {
   if (lane == 0) {
-    flag_store(a.ctrl + 1, blockIdx.x); flag_store(a.ctrl + 2, (unsigned)s);
+    flag_store(a.ctrl + 1, (unsigned)task_index()); flag_store(a.ctrl + 2, (unsigned)s);
     flag_store(a.ctrl + 3, seen); flag_store(a.ctrl + 4, want);
     drain();
     flag_store(a.ctrl, 1u);
@@ -88,8 +99,8 @@ __device__ __forceinline__ bool deps_ready(unsigned seen, unsigned want, unsigne
   return bad == 0;
 }
 #ifdef GREB_TUNING
-#define GREB_CIRC_WAITED(t0) if (a.timeline && lane == 0) a.timeline[3 * gridDim.x + blockIdx.x] += __builtin_amdgcn_s_memrealtime() - (t0)
-#define GREB_CIRC_DRAINED(t0) if (a.timeline && lane == 0) a.timeline[4 * gridDim.x + blockIdx.x] += __builtin_amdgcn_s_memrealtime() - (t0)
+#define GREB_CIRC_WAITED(t0) if (a.timeline && lane == 0) a.timeline[3 * a.n_tasks + task_index()] += __builtin_amdgcn_s_memrealtime() - (t0)
+#define GREB_CIRC_DRAINED(t0) if (a.timeline && lane == 0) a.timeline[4 * a.n_tasks + task_index()] += __builtin_amdgcn_s_memrealtime() - (t0)
 #else
 #define GREB_CIRC_WAITED(t0)
 #define GREB_CIRC_DRAINED(t0)
@@ -128,7 +139,7 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
   const LaneAddr L = lane_addr(lane);
   const unsigned lb = (unsigned)(size_t)lds;
   const bool calm = a.calm_odd && tracer;
-  unsigned* const my_flag = a.flags + blockIdx.x;
+  unsigned* const my_flag = a.flags + task_index();
   // rows outside the grid: fetched from the nearest row inside (finite values) and given weight zero below
   const int rm2 = r >= 2 ? r - 2 : 0, rm1 = r >= 1 ? r - 1 : 0, rp1 = r + 1 < ny ? r + 1 : ny - 1, rp2 = r + 2 < ny ? r + 2 : ny - 1;
   auto fetch = [&](const float* A, const float* B, unsigned at, auto aux) { // rows A and B -> the 3 KB slot at byte `at`
@@ -190,7 +201,7 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
   for (int s = 0; s < a.nsub; ++s) {
     float* dst = a.X[(s + 1) & 1] + (size_t)fld * np;
 #ifdef GREB_TUNING
-    if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[s] = __builtin_amdgcn_s_memrealtime();
+    if (a.stamps && task_index() == 0 && lane == 0) a.stamps[s] = __builtin_amdgcn_s_memrealtime();
 #endif
     const float (&T0)[6] = Tw[2];
     float Td[6], Ta[6];
@@ -284,30 +295,32 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
   }
   publish(my_flag, a.epoch0 + (unsigned)a.nsub, lane);
 #ifdef GREB_TUNING
-  if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[a.nsub] = __builtin_amdgcn_s_memrealtime();
+  if (a.stamps && task_index() == 0 && lane == 0) a.stamps[a.nsub] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
 template <bool STRICT>
-__global__ __launch_bounds__(64) void circ_rows_kernel(const CircArgs a) {
+__global__ __launch_bounds__(64 * kTasksPerGroup, 2) void circ_rows_kernel(const CircArgs a) {
   extern __shared__ __align__(16) float lds_raw[];
-  lfloat* lds = (lfloat*)lds_raw;
-  const ctask& tk = *(const ctask*)(a.tasks + blockIdx.x); // eight dwords through the scalar cache
+  const int task = task_index();
+  if (task >= a.n_tasks) return; // (the last workgroup of a launch whose task count is not a multiple of four)
+  lfloat* lds = (lfloat*)lds_raw + (size_t)(task & (kTasksPerGroup - 1)) * (kStepLdsB / 4);
+  const ctask& tk = *(const ctask*)(a.tasks + task); // eight dwords through the scalar cache
   int fld = tk.field;
   const int task_rows = tk.rows;
   const int d0 = tk.dep[0], d1 = tk.dep[1], d2 = tk.dep[2], d3 = tk.dep[3];
 #ifdef GREB_TUNING
-  if (a.timeline && threadIdx.x == 0) {
-    a.timeline[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  if (a.timeline && (threadIdx.x & 63) == 0) {
+    a.timeline[2 * task] = __builtin_amdgcn_s_memrealtime();
     unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); // wave, SIMD, CU, SE ids
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    a.timeline[2 * gridDim.x + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+    a.timeline[2 * a.n_tasks + task] = ((unsigned long long)xcc << 32) | hw;
   }
 #endif
   const int tab_idx = (int)((unsigned)fld >> kStepFieldBits);
   fld &= (1 << kStepFieldBits) - 1;
   const int k0 = task_rows & 0xff, k1 = (task_rows >> 8) & 0x1ff, ny = a.ny;
-  const unsigned lane = threadIdx.x;
+  const unsigned lane = threadIdx.x & 63;
   const int tracer = fld & 1;
   const crow_tables& tab = *(const crow_tables*)(a.tabs + tab_idx);
   // what this lane watches while the wavefront waits: lanes 0-3 a dependency each, lane 4 the abort word
@@ -325,12 +338,12 @@ __global__ __launch_bounds__(64) void circ_rows_kernel(const CircArgs a) {
 #ifdef GREB_TUNING
       const unsigned long long td = __builtin_amdgcn_s_memrealtime();
 #endif
-      publish(a.flags + blockIdx.x, a.epoch0 + (unsigned)s + 1u, lane);
+      publish(a.flags + task, a.epoch0 + (unsigned)s + 1u, lane);
       GREB_CIRC_DRAINED(td);
     }
   }
 #ifdef GREB_TUNING
-  if (a.timeline && threadIdx.x == 0) a.timeline[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  if (a.timeline && (threadIdx.x & 63) == 0) a.timeline[2 * task + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -504,14 +517,19 @@ hipError_t launch_circulation_rows(float* X0, float* X1, const float* W2, const 
   CircArgs a{};
   a.X[0] = X0; a.X[1] = X1; a.W2 = W2; a.u = u; a.v = v; a.tabs = tabs_dev; a.tasks = order.tasks;
   a.flags = order.flags; a.ctrl = order.ctrl; a.epoch0 = order.epoch; a.spin_ticks = kCircSpinTicks;
-  a.ny = ny; a.nsub = nsub; a.calm_odd = calm_vapor ? 1 : 0; a.chains_first = chains_first ? 1 : 0;
+  a.n_tasks = order.n; a.ny = ny; a.nsub = nsub; a.calm_odd = calm_vapor ? 1 : 0; a.chains_first = chains_first ? 1 : 0;
   a.chain_head = head; a.chain_tail = tail;
 #ifdef GREB_TUNING
   a.stamps = g_circ_stamps;
   a.timeline = order.n == g_circ_timeline_cap ? g_circ_timeline : nullptr;
 #endif
   auto kern = strict ? circ_rows_kernel<true> : circ_rows_kernel<false>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)order.n), dim3(64), kStepLdsB, s, a);
+  // (four wavefronts' LDS is more than the 64 KB a kernel may ask for by default; the same ceiling as every other kernel
+  // of the library, greb_kernels.h: kMaxDynamicLds -- set on every launch, it is idempotent and two host threads may race)
+  hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
+  if (ea != hipSuccess) return ea;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((order.n + kTasksPerGroup - 1) / kTasksPerGroup)), dim3(64 * kTasksPerGroup),
+                     kTasksPerGroup * kStepLdsB, s, a);
   order.epoch += (unsigned)nsub;
   return hipGetLastError();
 }

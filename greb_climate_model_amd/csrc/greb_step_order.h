@@ -18,7 +18,7 @@ namespace {
 // Two strips on one SIMD end after max(their walls, the sum of their issues): measured 94 000 cycles for a polar strip of
 // 63 500 beside a 16-row streaming strip (30 400 of issue), 61 000-70 000 for two such streaming strips.
 struct RowCost { int issue, wall; };
-constexpr int kRowIssue = 2200, kRowWall = 3500, kSweepCycles = 147, kChainSetupCycles = 850, kFillIssue = 700, kFillWall = 3800;
+constexpr int kRowIssue = 1900, kRowWall = 3500, kSweepCycles = 147, kChainSetupCycles = 850, kFillIssue = 700, kFillWall = 3800;
 RowCost step_row_cost(const RowTables& t, int k) {
   const int d = t.dif_time2[k], a = t.adv_time2[k];
   static const int row_issue = tuning_int("GREB_STEP_ROWCOST", kRowIssue); // -DGREB_TUNING builds only

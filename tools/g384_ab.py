@@ -19,8 +19,10 @@ for M in [int(x) for x in (sys.argv[1:] or ["1", "62"])]:
     if M > 1:
         o = ensemble.perturbed_physics(64, p); o = o[o[:, 3] >= 7.27e5][:M]
         ov = [dict(zip(ensemble.PERTURBED, map(float, r))) for r in o]
-    e = engine.Engine(inp, p, n_members=M, overrides=ov, strict=bool(os.environ.get('STRICT')))
+    pers = {None: None, '0': False, '1': True}[os.environ.get('PERSISTENT')]  # default: the engine's own trial
+    e = engine.Engine(inp, p, n_members=M, overrides=ov, strict=bool(os.environ.get('STRICT')), persistent=pers)
     buf = torch.empty((M, 1, 12, 5, e.np), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize(); t = time.perf_counter(); e.run(1, 680.0, monthly_dev_ptr=buf.data_ptr()); torch.cuda.synchronize(); dt = time.perf_counter() - t
-    print(f"members {M}: {M / dt:.2f} member-yr/s, {dt / (730 * 25) * 1e6:.1f} us per launch, finite={bool(torch.isfinite(buf).all())}", flush=True)
+    form = [c["form"] for c in e.describe().get("circulation", []) if c["members_run"] == M]
+    print(f"members {M}: {M / dt:.2f} member-yr/s, {dt / (730 * 24) * 1e6:.2f} us per sub-step, {form}, finite={bool(torch.isfinite(buf).all())}", flush=True)
     e.close(); del buf
