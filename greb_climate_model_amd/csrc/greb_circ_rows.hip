@@ -364,9 +364,10 @@ void circ_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members,
   const int n_simd = std::max(1, n_slots / 2);
   auto is_chain = [&](const RowTables& t, int k) { return t.dif_time2[k] >= chain_min; };
   // a chain task: its sweeps and set-up, the meridional part, no streaming
+  static const int chain_weight = tuning_int("GREB_CIRC_CHAIN_WEIGHT", 120); // per cent of the modelled cost: a chain task on a shared SIMD is the one that never waits (tools/circ_timeline.py), so it is dealt the cheaper partner
   auto chain_cost = [&](const RowTables& t, int k) {
     const RowCost c = step_row_cost(t, k);
-    return (long long)(c.issue - kRowIssue + 800);
+    return (long long)(c.issue - kRowIssue + 800) * chain_weight / 100;
   };
   long long total = 0, dearest = 0;
   for (int m = 0; m < n_members; ++m)
