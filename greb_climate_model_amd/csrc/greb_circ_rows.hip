@@ -130,11 +130,11 @@ __device__ bool wait_deps(const CircArgs& a, const unsigned* mine, unsigned want
 // operands have been read out of it.
 constexpr unsigned kHaloBase = kRingBase, kStageBase = kWindBase, kPollBase = kWindBase;
 
-template <bool STRICT>
+template <bool STRICT, int NXR>
 __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const crow_tables& tab, int fld, int r,
                                            const unsigned* mine, unsigned lane) {
   const int ny = a.ny, tracer = fld & 1;
-  const size_t np = (size_t)kNx * ny;
+  const size_t np = (size_t)NXR * ny;
   const float* wf = a.W2 + (size_t)tracer * np;
   const LaneAddr L = lane_addr(lane);
   const unsigned lb = (unsigned)(size_t)lds;
@@ -143,20 +143,20 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
   // rows outside the grid: fetched from the nearest row inside (finite values) and given weight zero below
   const int rm2 = r >= 2 ? r - 2 : 0, rm1 = r >= 1 ? r - 1 : 0, rp1 = r + 1 < ny ? r + 1 : ny - 1, rp2 = r + 2 < ny ? r + 2 : ny - 1;
   auto fetch = [&](const float* A, const float* B, unsigned at, auto aux) { // rows A and B -> the 3 KB slot at byte `at`
-    issue_pair<decltype(aux)::value>(A, B, second_halves(A, B, lane), lds + at / 4, lane);
+    issue_pair_p<decltype(aux)::value>(pair_ptrs<NXR>(A, B, lane), 0, lds + at / 4);
   };
   using plain = std::integral_constant<int, kAuxPlain>;
   using sc1 = std::integral_constant<int, kAuxSc1>;
   auto fetch_halo = [&](const float* Xf, int buf) { // rows r-2, r-1 | r+1, r+2 of the field as it stands in Xf
-    fetch(Xf + rm2 * kNx, Xf + rm1 * kNx, kHaloBase + (2 * buf) * kSlotB, sc1{});
-    fetch(Xf + rp1 * kNx, Xf + rp2 * kNx, kHaloBase + (2 * buf + 1) * kSlotB, sc1{});
+    fetch(Xf + rm2 * NXR, Xf + rm1 * NXR, kHaloBase + (2 * buf) * kSlotB, sc1{});
+    fetch(Xf + rp1 * NXR, Xf + rp2 * NXR, kHaloBase + (2 * buf + 1) * kSlotB, sc1{});
   };
   // ---- once per call: the row, its weights and winds, the neighbours' weights; all in flight together
   const float* X0 = a.X[0] + (size_t)fld * np;
-  fetch(wf + rm2 * kNx, wf + rm1 * kNx, kStageBase, plain{});
-  fetch(wf + rp1 * kNx, wf + rp2 * kNx, kStageBase + kSlotB, plain{});
-  fetch(X0 + r * kNx, wf + r * kNx, kHaloBase + 2 * kSlotB, sc1{});
-  fetch(a.u + r * kNx, a.v + r * kNx, kHaloBase + 3 * kSlotB, plain{});
+  fetch(wf + rm2 * NXR, wf + rm1 * NXR, kStageBase, plain{});
+  fetch(wf + rp1 * NXR, wf + rp2 * NXR, kStageBase + kSlotB, plain{});
+  fetch(X0 + r * NXR, wf + r * NXR, kHaloBase + 2 * kSlotB, sc1{});
+  fetch(a.u + r * NXR, a.v + r * NXR, kHaloBase + 3 * kSlotB, plain{});
   fetch_halo(X0, 0);
   drain();
   float Tw[5][6], ww[5][6], u[6], v[6];
@@ -175,7 +175,7 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
   const float ccy_dif = tab.dif_ccy, ccy_adv = tab.adv_ccy;
   const int t2d = tab.dif_time2[r], t2a = tab.adv_time2[r];
   const float ccd = tab.dif_ccx2[r], cca = tab.adv_ccx2[r];
-  const bool last_lane = lane == 63;
+  const bool last_lane = bug_lane<NXR>(lane);
   float wc[12];
   chain_halo(ww[2], wc);
   const float u0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -213,7 +213,7 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
     if (STRICT) {
       float Tc[12];
       chain_halo(T0, Tc);
-      chain_window<true, 6>(Tc, wc, u, cca, t2a, true, (int)lane, false);
+      chain_window<true, 6>(Tc, wc, u, cca, t2a, true, last_lane ? 63 : 0, false); // (63: the lane with the :881 index bug)
 #pragma unroll
       for (int j = 0; j < 6; ++j) Ta[j] = Tc[3 + j];
       chain_halo(T0, Tc);
@@ -226,7 +226,7 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
           for (int j = 0; j < 6; ++j) own[j] = Tc[3 + j];
           chain_halo(own, Tc);
         }
-        chain_window<true, 6>(Tc, wc, u0, ccd, n, false, (int)lane, false);
+        chain_window<true, 6>(Tc, wc, u0, ccd, n, false, last_lane ? 63 : 0, false);
         done += n;
       };
       part(head);
@@ -286,9 +286,7 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
     meridional_update<STRICT>(Tw, ww, Td, Ta, v, ccy_dif, ccy_adv, r, ny, o);
     vfloat4 q0, q1;
     transpose_out(L, lb + kOutBase, o, q0, q1);
-    float* row = dst + r * kNx;
-    store16<true>(row + 4 * lane, q0);
-    if (lane < 32) store16<true>(row + 256 + 4 * lane, q1);
+    (void)store_row_quads<NXR>(dst + r * NXR, lane, q0, q1, [](float* p_, vfloat4 q_) { store16<true>(p_, q_); });
     order_fence();
 #pragma unroll
     for (int j = 0; j < 6; ++j) Tw[2][j] = o[j];
@@ -299,7 +297,7 @@ __device__ __forceinline__ void chain_task(lfloat* lds, const CircArgs& a, const
 #endif
 }
 
-template <bool STRICT>
+template <bool STRICT, int NXR>
 __global__ __launch_bounds__(64 * kTasksPerGroup, 2) void circ_rows_kernel(const CircArgs a) {
   extern __shared__ __align__(16) float lds_raw[];
   const int task = task_index();
@@ -327,14 +325,14 @@ __global__ __launch_bounds__(64 * kTasksPerGroup, 2) void circ_rows_kernel(const
   const int dep = lane == 0 ? d0 : (lane == 1 ? d1 : (lane == 2 ? d2 : (lane == 3 ? d3 : -1)));
   const unsigned* mine = lane == 4 ? a.ctrl : (dep >= 0 ? a.flags + dep : nullptr);
   if (task_rows & kCircChain) {
-    chain_task<STRICT>(lds, a, tab, fld, k0, mine, lane);
+    chain_task<STRICT, NXR>(lds, a, tab, fld, k0, mine, lane);
   } else {
-    const size_t np = (size_t)kNx * ny;
+    const size_t np = (size_t)NXR * ny;
     const StripStamps st{nullptr, nullptr};
     for (int s = 0; s < a.nsub; ++s) {
       if (s > 0 && !wait_deps(a, mine, a.epoch0 + (unsigned)s, lane, s)) return;
       const StripIo io{a.X[s & 1] + (size_t)fld * np, a.W2 + (size_t)tracer * np, a.X[(s + 1) & 1] + (size_t)fld * np, a.u, a.v};
-      stream_strip<STRICT, kAuxSc1, true>(lds, io, tab, k0, k1, ny, a.calm_odd && tracer, a.chains_first, lane, st);
+      stream_strip<STRICT, kAuxSc1, true, NXR>(lds, io, tab, k0, k1, ny, a.calm_odd && tracer, a.chains_first, lane, st);
 #ifdef GREB_TUNING
       const unsigned long long td = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -509,9 +507,9 @@ extern "C" int greb_tuning_circ_timeline(unsigned long long* out, int capacity) 
 #endif
 
 hipError_t launch_circulation_rows(float* X0, float* X1, const float* W2, const float* u, const float* v,
-                                   const RowTables* tabs_dev, CircOrder& order, int n_simd, int ny, int nsub, bool strict,
+                                   const RowTables* tabs_dev, CircOrder& order, int n_simd, int nx, int ny, int nsub, bool strict,
                                    hipStream_t s, bool calm_vapor) {
-  if (order.n <= 0 || order.n > 2 * n_simd || nsub < 1) return hipErrorInvalidValue; // more tasks than wavefront slots: never launched
+  if (order.n <= 0 || order.n > 2 * n_simd || nsub < 1 || (nx != kNx && 2 * nx != kNx)) return hipErrorInvalidValue; // more tasks than wavefront slots: never launched
   static const int forced = tuning_int("GREB_STEP_CHAINS_FIRST", -1); // -DGREB_TUNING builds only (A/B)
   static const int head = tuning_int("GREB_CIRC_HEAD", 8), tail = tuning_int("GREB_CIRC_TAIL", 24);
   const bool chains_first = forced >= 0 ? forced != 0 : order.n <= n_simd;
@@ -524,7 +522,8 @@ hipError_t launch_circulation_rows(float* X0, float* X1, const float* W2, const 
   a.stamps = g_circ_stamps;
   a.timeline = order.n == g_circ_timeline_cap ? g_circ_timeline : nullptr;
 #endif
-  auto kern = strict ? circ_rows_kernel<true> : circ_rows_kernel<false>;
+  auto kern = nx == kNx ? (strict ? circ_rows_kernel<true, kNx> : circ_rows_kernel<false, kNx>)
+                        : (strict ? circ_rows_kernel<true, kNx / 2> : circ_rows_kernel<false, kNx / 2>);
   // (four wavefronts' LDS is more than the 64 KB a kernel may ask for by default; the same ceiling as every other kernel
   // of the library, greb_kernels.h: kMaxDynamicLds -- set on every launch, it is idempotent and two host threads may race)
   hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);

@@ -320,14 +320,14 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
       } else form = (s >= 2 && s < 5) ? 1 : 2;
     }
     if (form == 2) {
-      HIP_TRY(e, launch_circulation_rows(e->Xa, e->Xb, e->W2, e->uclim + off, e->vclim + off, e->tabs, *circ, e->cus * 4, e->ny,
+      HIP_TRY(e, launch_circulation_rows(e->Xa, e->Xb, e->W2, e->uclim + off, e->vclim + off, e->tabs, *circ, e->cus * 4, e->nx, e->ny,
                                          a.nsub, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
       if (a.nsub & 1) cur = e->Xb;
     } else
     for (int tt = 0; tt < a.nsub; ++tt) {
       if (rows)
         HIP_TRY(e, launch_substep_rows(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, step_tasks,
-                                       step_head, n_step_tasks, e->cus * 4, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
+                                       step_head, n_step_tasks, e->cus * 4, e->nx, e->ny, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));
       else
         HIP_TRY(e, launch_substep_fused(cur, e->W2, e->uclim + off, e->vclim + off, nxt, e->tabs, e->tab_index, e->nx,
                                         e->ny, nrun, e->strict, e->stream, (e->xsw & GREB_X_VAPOR_DIFFUSION_ONLY) != 0));

@@ -108,7 +108,7 @@ hipError_t step_rows_make_tasks(const RowTables* tabs_host, const int* tab_index
                                 int n_slots, RowsTask** dev, int* n, RowsTask* head /* [kStepHeadTasks] */);
 hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
                                const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, const RowsTask* head_host,
-                               int n_tasks, int n_simd, int ny, bool strict, hipStream_t s, bool calm_vapor);
+                               int n_tasks, int n_simd, int nx, int ny, bool strict, hipStream_t s, bool calm_vapor);
 // greb_circ_rows.hip: the circulation CALL (all its sub-steps, src/greb.f90:546-550) on a 384-wide grid in ONE launch.
 // The strips of a field hand their rows to each other through memory flags, so every task of the launch must be
 // resident at once: the caller passes the wavefront slots it may use and the builder never makes more tasks than that.
@@ -136,7 +136,7 @@ hipError_t circ_rows_make_order(const RowTables* tabs_host, const int* tab_index
 void circ_rows_free_order(CircOrder* o);
 // X[0] / X[1]: sub-step s reads X[s & 1] and writes X[(s + 1) & 1]; the result is in X[nsub & 1]
 hipError_t launch_circulation_rows(float* X0, float* X1, const float* W2, const float* u, const float* v,
-                                   const RowTables* tabs_dev, CircOrder& order, int n_simd, int ny, int nsub, bool strict,
+                                   const RowTables* tabs_dev, CircOrder& order, int n_simd, int nx, int ny, int nsub, bool strict,
                                    hipStream_t s, bool calm_vapor);
 // after the stream has been synchronised: 0, or -1 with the strip that gave up waiting in msg[0..4] (ctrl[1..5])
 int circ_rows_status(const CircOrder& o, unsigned* diag5);

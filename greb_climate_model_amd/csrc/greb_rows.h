@@ -89,6 +89,50 @@ __device__ __forceinline__ const float* second_halves(const float* A, const floa
   return lane < 32 ? A + 256 + 4 * lane : B + 256 + 4 * (lane - 32);
 }
 
+// The same machinery on a grid HALF as wide (NXR = 192: the 192x96 grid): the wavefront holds the row TWICE, lanes 32-63
+// a copy of lanes 0-31.  A latitude circle laid twice around the wavefront's ring of 64 lanes is still that circle --
+// lane 31's eastern neighbour is lane 32 = the copy of lane 0, lane 0's western neighbour is lane 63 = the copy of lane
+// 31 -- so every wave rotate (the zonal halo, the 33-instruction chain sweep of greb_chain6.h) is right as it stands; the
+// copy is made by the LDS-DMA's per-lane source addresses (virtual longitude v of the 384 -> v mod 192) and only lanes
+// 0-47 store.  Twice the arithmetic per point, none of it new code.
+template <int NXR>
+__device__ __forceinline__ int ring_wrap(int v) { // virtual longitude (0 .. 383) -> longitude of the row
+  static_assert(NXR == kNx || 2 * NXR == kNx, "the row fills the wavefront's 384 longitudes once or twice");
+  return (NXR < kNx && v >= NXR) ? v - NXR : v;
+}
+// the per-lane sources of the three LDS-DMA instructions of a pair of rows A, B (pointers to the rows' first longitude)
+struct PairPtrs { const float* p1; const float* p2; const float* p3; };
+template <int NXR>
+__device__ __forceinline__ PairPtrs pair_ptrs(const float* A, const float* B, unsigned lane) {
+  const int l = (int)lane;
+  return PairPtrs{A + ring_wrap<NXR>(4 * l), l < 32 ? A + ring_wrap<NXR>(256 + 4 * l) : B + ring_wrap<NXR>(256 + 4 * (l - 32)),
+                  B + ring_wrap<NXR>(4 * l)};
+}
+// rows A + off, B + off (off: floats, wave-uniform) -> the slot at dst
+template <int AUX>
+__device__ __forceinline__ void issue_pair_p(const PairPtrs& P, int off, lfloat* dst) {
+  glds16<AUX>(P.p1 + off, dst);
+  glds16<AUX>(P.p2 + off, dst + 256);
+  glds16<AUX>(P.p3 + off, dst + 512);
+  order_fence();
+}
+// the lane whose point 3 is longitude xdim-2 (1-based) of its copy of the row: the reference's index bug (:881)
+template <int NXR>
+__device__ __forceinline__ bool bug_lane(unsigned lane) { return (lane & (NXR / 6 - 1)) == (unsigned)(NXR / 6 - 1); }
+// sixteen result bytes per lane -> the row at `row` (its first longitude): 64 + 32 lanes for 384 longitudes, 48 for 192;
+// returns the number of store instructions issued (wave-uniform: the hand-counted vmcnt needs it exact)
+template <int NXR, typename Store>
+__device__ __forceinline__ int store_row_quads(float* row, unsigned lane, vfloat4 q0, vfloat4 q1, Store&& st) {
+  if constexpr (NXR == kNx) {
+    st(row + 4 * lane, q0);
+    if (lane < 32) st(row + 256 + 4 * lane, q1);
+    return 2;
+  } else {
+    if (4 * lane < (unsigned)NXR) st(row + 4 * lane, q0);
+    return 1;
+  }
+}
+
 // three LDS-DMA instructions: rows A and B (wave-uniform pointers to the rows) -> the slot at dst
 template <int AUX>
 __device__ __forceinline__ void issue_pair(const float* a_row, const float* b_row, const float* halves_row, lfloat* dst,

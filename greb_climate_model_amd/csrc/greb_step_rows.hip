@@ -50,7 +50,7 @@ struct StepArgs {
   unsigned long long* stamps; // -DGREB_TUNING builds only (null otherwise): s_memtime stamps of task 0
   unsigned long long* timeline; // -DGREB_TUNING builds only: [task][start, end] in s_memrealtime ticks (100 MHz) + [2 n]: hw id
 };
-template <bool STRICT>
+template <bool STRICT, int NXR>
 __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
   extern __shared__ __align__(16) float lds_raw[];
   lfloat* lds = (lfloat*)lds_raw;
@@ -82,14 +82,14 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
   const int tracer = fld & 1;
   // the row table through the constant address space (greb_step_strip.h: crow_tables)
   const crow_tables& tab = *(const crow_tables*)(a.tabs + tab_idx); // (index in the task word: one dependent latency less)
-  const size_t np = (size_t)kNx * ny;
+  const size_t np = (size_t)NXR * ny;
   const StripIo io{a.X + (size_t)fld * np, a.W2 + (size_t)tracer * np, a.Xnew + (size_t)fld * np, a.u, a.v};
   StripStamps st{nullptr, nullptr};
 #ifdef GREB_TUNING
   if (a.stamps && blockIdx.x == 0) st.first = a.stamps;
   if (a.stamps && blockIdx.x == (gridDim.x * 3) / 4) st.phases = a.stamps; // a task three quarters down the launch order
 #endif
-  stream_strip<STRICT, kAuxPlain, false>(lds, io, tab, k0, k1, ny, a.calm_odd && tracer, a.chains_first, lane, st);
+  stream_strip<STRICT, kAuxPlain, false, NXR>(lds, io, tab, k0, k1, ny, a.calm_odd && tracer, a.chains_first, lane, st);
 #ifdef GREB_TUNING
   if (a.timeline && threadIdx.x == 0) a.timeline[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
 } // namespace
 
 bool step_rows_supported(const RowTables* tabs, int n_tabs, int nx, int ny) {
-  if (nx != rows::kNx || ny < 5 || ny > kMaxNy) return false;
+  if ((nx != rows::kNx && 2 * nx != rows::kNx) || ny < 5 || ny > kMaxNy) return false; // 384 longitudes, or 192 laid twice round the wavefront
   for (int t = 0; t < n_tabs; ++t)
     for (int k = 0; k < ny; ++k)
       if (!tabs[t].subcycled[k] || tabs[t].dif_time2[k] < 1 || tabs[t].adv_time2[k] < 1) return false;
@@ -210,7 +210,7 @@ extern "C" int greb_tuning_step_stamps(unsigned long long* out6) {
 
 hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, const float* v, float* Xnew,
                                const RowTables* tabs_dev, const int* tab_index_dev, const RowsTask* tasks, const RowsTask* head_host,
-                               int n_tasks, int n_simd, int ny, bool strict, hipStream_t s, bool calm_vapor) {
+                               int n_tasks, int n_simd, int nx, int ny, bool strict, hipStream_t s, bool calm_vapor) {
   // A chain never waits, so at equal priority (it is the older wavefront) it takes every issue slot of its SIMD and the
   // streaming strip beside it -- which needs few slots but a long time, it waits for memory -- stands still until the
   // chain is over.  Where SIMDs are shared (more tasks than SIMDs) the streaming rows therefore issue first and the
@@ -225,7 +225,8 @@ hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, 
   a.stamps = g_step_stamps;
   a.timeline = n_tasks <= g_step_timeline_cap ? g_step_timeline : nullptr;
 #endif
-  auto kern = strict ? step_rows_kernel<true> : step_rows_kernel<false>;
+  auto kern = nx == kNx ? (strict ? step_rows_kernel<true, kNx> : step_rows_kernel<false, kNx>)
+                        : (strict ? step_rows_kernel<true, kNx / 2> : step_rows_kernel<false, kNx / 2>);
   hipLaunchKernelGGL(kern, dim3((unsigned)n_tasks), dim3(64), kStepLdsB, s, a);
   return hipGetLastError();
 }

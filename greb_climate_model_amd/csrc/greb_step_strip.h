@@ -1,6 +1,6 @@
 // greb_step_strip.h -- one circulation sub-step X <- (X + dX_diffuse) + dX_advec (src/greb.f90:549, with :556-723 and
-// :726-915 behind it) for a STRIP of consecutive latitude rows of one (member, tracer) field of a 384-wide grid, worked
-// by one wavefront.  Shared by the two kernels that run it:
+// :726-915 behind it) for a STRIP of consecutive latitude rows of one (member, tracer) field of a 384-wide grid -- or of a
+// 192-wide one, the row laid twice around the wavefront (greb_rows.h: NXR) --, worked by one wavefront.  Shared by the two kernels that run it:
 //   greb_step_rows.hip   one launch per sub-step (plain loads and stores; the kernel boundary orders the sub-steps);
 //   greb_circ_rows.hip   one launch per circulation CALL: the 24 sub-steps (src/greb.f90:546-550) in one kernel, the
 //                        strips handing their rows to their neighbours through memory flags (loads and stores of the
@@ -117,29 +117,29 @@ struct StripIo {
 
 // Rows [k0, k1) of one field, one sub-step.  On entry the wavefront has no vector-memory operation outstanding (vmcnt is
 // counted by hand from zero); on exit the stores of the last rows may still be in flight.
-template <bool STRICT, int AUX_X, bool SC1>
+template <bool STRICT, int AUX_X, bool SC1, int NXR = kNx>
 __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, const crow_tables& tab, int k0, int k1, int ny,
                                              bool calm, int chains_first, unsigned lane, const StripStamps& st) {
   const float* Xf = io.Xf;
   const float* wf = io.wf;
   float* of = io.of;
-  const float* hXw = second_halves(Xf, wf, lane);
-  const float* hUV = second_halves(io.u, io.v, lane);
+  const PairPtrs PX = pair_ptrs<NXR>(Xf, wf, lane), PU = pair_ptrs<NXR>(io.u, io.v, lane);
   const LaneAddr L = lane_addr(lane);
   const unsigned lb = (unsigned)(size_t)lds;
-  const bool last_lane = lane == 63;
+  const bool last_lane = bug_lane<NXR>(lane);
+  constexpr int kStores = NXR == kNx ? 2 : 1; // store instructions per row (store_row_quads)
   if (!chains_first) __builtin_amdgcn_s_setprio(2); // streaming rows ahead of the chains (which drop to 0 while they sweep)
   int ops = 0;
   unsigned long long gT = 0, gU = 0; // 16 bits per slot: `ops` right after the slot's LDS-DMA was issued
   auto issue_T = [&](int row) {
     const int slot = row & (kRing - 1);
-    issue_pair<AUX_X>(Xf + row * kNx, wf + row * kNx, hXw + row * kNx, lds + (kRingBase + slot * kSlotB) / 4, lane);
+    issue_pair_p<AUX_X>(PX, row * NXR, lds + (kRingBase + slot * kSlotB) / 4);
     ops += 3;
     gT = (gT & ~(0xffffull << (16 * slot))) | ((unsigned long long)ops << (16 * slot));
   };
   auto issue_U = [&](int row) {
     const int slot = row & 1;
-    issue_pair<kAuxPlain>(io.u + row * kNx, io.v + row * kNx, hUV + row * kNx, lds + (kWindBase + slot * kSlotB) / 4, lane);
+    issue_pair_p<kAuxPlain>(PU, row * NXR, lds + (kWindBase + slot * kSlotB) / 4);
     ops += 3;
     gU = (gU & ~(0xffffull << (16 * slot))) | ((unsigned long long)ops << (16 * slot));
   };
@@ -161,8 +161,8 @@ __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, con
     PairRaw raw;
     if (have) {
       const int slot = row & (kRing - 1);
-      // (mid-strip the row was requested four steps ago: 2 + 3 x 8 + 3 operations since)
-      wait_all_but_mostly<29>(ops - (int)((gT >> (16 * slot)) & 0xffff));
+      // (mid-strip the row was requested four steps ago: 2 + 3 x 8 + 3 operations since, at two stores per row)
+      wait_all_but_mostly<23 + 3 * kStores>(ops - (int)((gT >> (16 * slot)) & 0xffff));
       read_pair_issue(L, lb + kRingBase + slot * kSlotB, raw); // ... and the window shifts under the LDS latency
     }
 #pragma unroll
@@ -230,14 +230,14 @@ __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, con
       GREB_STEP_STAMP(2);
       if (STRICT || t2d > 1) {
         if (!chains_first) __builtin_amdgcn_s_setprio(0);
-        chain_window<STRICT, 6>(Tc, wc, u0, ccd, t2d, false, (int)lane, chains_first != 0);
+        chain_window<STRICT, 6>(Tc, wc, u0, ccd, t2d, false, last_lane ? 63 : 0, chains_first != 0);
 #pragma unroll
         for (int j = 0; j < 6; ++j) Td[j] = Tc[3 + j];
       }
       GREB_STEP_STAMP(3);
       if (STRICT || t2a > 1) {
         if (!chains_first) __builtin_amdgcn_s_setprio(0);
-        chain_window<STRICT, 6>(T2, wc, u, cca, t2a, true, (int)lane, chains_first != 0);
+        chain_window<STRICT, 6>(T2, wc, u, cca, t2a, true, last_lane ? 63 : 0, chains_first != 0); // (63: the lane with the :881 index bug)
 #pragma unroll
         for (int j = 0; j < 6; ++j) Ta[j] = T2[3 + j];
       }
@@ -256,15 +256,12 @@ __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, con
     meridional_update<STRICT>(Tw, ww, Td, Ta, v, ccy_dif, ccy_adv, r, ny, o);
     vfloat4 q0, q1;
     transpose_out(L, lb + kOutBase, o, q0, q1);
-    float* row = of + r * kNx;
-    store16<SC1>(row + 4 * lane, q0);
-    if (lane < 32) store16<SC1>(row + 256 + 4 * lane, q1);
+    ops += store_row_quads<NXR>(of + r * NXR, lane, q0, q1, [](float* p_, vfloat4 q_) { store16<SC1>(p_, q_); });
     order_fence();
-    ops += 2;
     GREB_STEP_STAMP(5);
     GREB_STEP_PHASE(3);
     if (r + 1 < k1) { // the next row's winds (requested at the start of the previous step: 13 operations since, mid-strip)
-      wait_all_but_mostly<13>(ops - (int)((gU >> (16 * ((r + 1) & 1))) & 0xffff));
+      wait_all_but_mostly<11 + kStores>(ops - (int)((gU >> (16 * ((r + 1) & 1))) & 0xffff));
       read_pair(L, lb + kWindBase + ((r + 1) & 1) * kSlotB, u, v);
     }
     GREB_STEP_PHASE(4);

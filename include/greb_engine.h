@@ -99,8 +99,15 @@ typedef struct greb_member_overrides {
 typedef struct greb_engine greb_engine;
 
 /* Create an engine for n_members ensemble members on HIP device `device`.
- * Any grid with nx % 4 == 0, ny <= 192: 96x48 runs the fused member kernel (whole member resident
- * in one CU), other grids the multi-launch engine.
+ * Any grid with nx % 4 == 0, nx >= 12, 5 <= ny <= 192 (src/greb.f90:36 is the only thing that fixes the grid in the
+ * reference).  Which kernels a grid gets:
+ *   96x48 with the default sub-cycling layout   the fused member kernel (a whole member resident in one compute unit);
+ *   nx = 384 or nx = 192                        the any-grid engine on wavefront-sized row strips (a lane owns six
+ *                                               longitudes; a 192-wide row is laid twice around the wavefront);
+ *   anything else                               the any-grid engine on latitude bands staged in LDS.
+ * What bounds ny: the per-row tables (sub-cycle counts and constants, src/greb.f90:578-582, 652-654, 838-840) are
+ * fixed-size arrays of 192 rows that travel by value in kernel arguments and sit in LDS, and a strip's rows are packed
+ * k0 in 8 and k1 in 9 bits of a task word; ny > 192 is GREB_E_INVALID, not a slower path.
  * Copies the inputs to HBM, computes the derived fields of greb_model's preamble
  * (src/greb.f90:176-216) and Toclim (src/greb.f90:1088-1094) and sets every member's
  * state to the initial state (src/greb.f90:194-197).  overrides may be NULL. */

@@ -699,10 +699,28 @@ def test_engine_g192_vs_reference(eng_mod, oracle_lib):
             ulp = float(np.spacing(np.float32(np.abs(X[i]).max())))
             assert np.abs(fast[i].astype(np.float64) - ref[i]).max() <= (8 if name == "crc" else 2) * ulp + 4e-6 * np.abs(ref[i]).max(), (name, i)
     ref = gs["monthly"]
-    for strict in (True, False):
-        e = eng_mod.Engine(inp, p, strict=strict)
+    # STRICT on the latitude bands; FAST on the row strips (the default there since round 4: the 192-wide row laid twice
+    # around the wavefront, greb_rows.h -- one launch per circulation call and one per sub-step); STRICT on the strips too
+    runs = {}
+    for label, kw in (("strict bands", dict(strict=True)), ("fast strips, one launch per call", dict(persistent=True)),
+                      ("fast strips, one launch per sub-step", dict(persistent=False)),
+                      ("strict strips, one launch per call", dict(strict=True, row_strips=True, persistent=True)),
+                      ("strict strips, one launch per sub-step", dict(strict=True, row_strips=True, persistent=False))):
+        e = eng_mod.Engine(inp, p, **kw)
+        d = e.describe()
+        assert d["engine"] == "row strips", d  # this grid takes the strips (STRICT without row_strips keeps its bands at run time)
         yf = e.flux_correction(1)
         mon, yr = e.run(1, 680.0)
+        d = e.describe()
         e.close()
-        _check_run(mon[0, 0], ref, f"g192 strict={strict}")
+        forms = [c["form"] for c in d.get("circulation", [])]
+        if "strips" in label:
+            assert forms == ["one launch per call" if "per call" in label else "one launch per sub-step"] or (not forms and "sub-step" in label), (label, d)
+        strict = label.startswith("strict")
+        _check_run(mon[0, 0], ref, f"g192 {label}")
         yearly_close(np.concatenate([yf[0], yr[0]]), gs["yearly"], strict, 192 * 96)
+        runs[label] = (mon, yr, yf)
+    for a, b in (("strict bands", "strict strips, one launch per call"), ("strict bands", "strict strips, one launch per sub-step"),
+                 ("fast strips, one launch per call", "fast strips, one launch per sub-step")):
+        for x, y in zip(runs[a], runs[b]):
+            assert np.array_equal(x, y), (a, b)  # the same arithmetic through different data movement: bit for bit
