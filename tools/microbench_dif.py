@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from greb_climate_model_amd import engine
-if os.environ.get("GREB_TUNING_LIB"):  # GREB_DEBUG_* knobs exist only in the -DGREB_TUNING library; the counter passes
+if os.environ.get("GREB_TUNING_LIB") or os.environ.get("GREB_LIB"):  # GREB_DEBUG_* knobs exist only in the -DGREB_TUNING library; the counter passes
     engine.use_tuning_build()         # (tools/prof_rows.sh, verify_round.sh) run the release library, whose code hash they record
 if os.environ.get("GREB_LIB"):
     engine._lib_path = os.path.abspath(os.environ["GREB_LIB"])  # a variant library (A/B of compile-time choices)
