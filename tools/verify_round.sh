@@ -10,7 +10,7 @@ set -e
 cd "$(dirname "$0")/.."
 R=${ROUND:-r04}
 python -c "import __graft_entry__ as g; g.build(); print('build ok')"
-if [ "$1" != profiles-only ]; then python -m pytest tests -x -q -m "not gpu" --deselect tests/test_profiles_cpu.py; fi
+if [ "$1" != profiles-only ] && [ -z "$SKIP_CPU" ]; then python -m pytest tests -x -q -m "not gpu" --deselect tests/test_profiles_cpu.py; fi
 [ "$1" = gpu ] || [ "$1" = profiles ] || [ "$1" = profiles-only ] || exit 0
 G=/usr/local/graft/bin/gpurun
 if [ "$1" != profiles-only ]; then
