@@ -97,9 +97,9 @@ void rows_tasks(const RowTables& t, int ny, int batch, const RowsTuning& tu, std
 void rows_release_cache();
 hipError_t launch_diffusion_rows(const float* T1, const float* wz, float* dX, const RowTables& t, int ny, int batch,
                                  bool strict, hipStream_t s);
-// greb_step_rows.hip: the engine's circulation sub-step on a 384-wide grid as wavefront-sized row strips
+// greb_step_rows.hip: the engine's circulation sub-step on a 384- or 192-wide grid as wavefront-sized row strips, one launch each
 bool step_rows_supported(const RowTables* tabs, int n_tabs, int nx, int ny);
-constexpr int kStepRowsSlotsPerCu = 8; // wavefronts of the sub-step kernel a CU holds (187 VGPRs, 19.5 KB of LDS each)
+constexpr int kStepRowsSlotsPerCu = 8; // wavefronts of the row-strip circulation kernels a CU holds (177-201 VGPRs: two per SIMD; 19.5 KB of LDS each)
 void step_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members, int ny, int n_slots,
                      std::vector<RowsTask>& tasks);
 constexpr int kStepFieldBits = 16;  // a sub-step task's field word: field | row-table index << 16 (at most 32 767 members)

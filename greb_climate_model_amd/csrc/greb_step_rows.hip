@@ -1,23 +1,17 @@
-// greb_step_rows.hip -- one circulation sub-step X <- (X + dX_diffuse) + dX_advec (src/greb.f90:549, with :556-723 and
-// :726-915 behind it) of the any-grid engine on 384-wide grids, as ROW STRIPS: the engine-side twin of greb_rows.hip.
+// greb_step_rows.hip -- ONE circulation sub-step X <- (X + dX_diffuse) + dX_advec (src/greb.f90:549, with :556-723 and
+// :726-915 behind it) of the any-grid engine on 384- and 192-wide grids per LAUNCH, as row strips: one wavefront = one
+// task = a strip of consecutive latitude rows of one (member, tracer) field (greb_step_strip.h has the strip itself and is
+// shared with greb_circ_rows.hip, which runs all 24 sub-steps of a circulation call in one launch).  No workgroup, no
+// barrier; the kernel boundary orders the sub-steps, so nothing here waits for another wavefront: this is the form the
+// engine takes where a one-launch call cannot be resident as a whole (greb_engine.cpp: the slot ledger), where
+// GREB_F_NO_PERSISTENT asks for it, or where the engine's own trial finds it faster.
 //
-// One wavefront = one task = a strip of consecutive latitude rows of one (member, tracer) field; no workgroup, no
-// barrier: a wave that owns a 232-sweep polar row (225 diffusion + 7 advection sweeps) starts its chain
-// as soon as ITS row and wind have landed and nobody else waits for it.  With few fields that chain is the length of the
-// launch (138-147 cycles per sweep -- greb_chain6.h: one instruction per 4.0 cycles, no test between the sweeps -- so
-// 14.9 us for that row with its set-up and epilogue, tools/stamp_step_rows.py); the band kernels (greb_kernels.hip:
-// sweep_kernel<fused>, and round 2's (Tair,q)-pair band kernel) add staging, a workgroup barrier and the band's epilogue
-// to it: 25.1 us per launch for one member, 48 us for 62 -- here 18 and 38.5.  With many fields the launch is bound by
-// instruction issue (one vector instruction per SIMD every 4 cycles) and by how evenly the SIMDs are loaded:
-// step_rows_tasks below.
-//   * rows k-2 .. k+2 of the tracer and its weight (the meridional stencils of both operators) are a window in registers
-//     that slides up one row per step; rows arrive by LDS-DMA up to three ahead of it (greb_rows.h: four landing slots,
-//     19.5 KB of LDS per wavefront, eight wavefronts per CU); the zonal halo is a wave rotate (DPP);
-//   * the winds of the row travel the same way (a ring of two);
-//   * per row: the zonal edge fluxes once, shared by the diffusion and the advection sweep (greb_device.h: edge-flux
-//     form); rows that iterate run their sweeps in registers (greb_chain6.h), diffusion and advection chains one after
-//     the other in the same wave;
-//   * the launch order is ONE round of at most as many tasks as the chip has wavefront slots (step_rows_tasks).
+// With few fields the launch is the 232-sweep polar row (225 diffusion + 7 advection sweeps, SURVEY.md App. B: 138-147
+// cycles per sweep, greb_chain6.h) plus everything in front of it -- arguments, task, the first rows from memory another
+// XCD wrote: 18.6-18.8 us per launch for one member (the one-launch call: 15.3 us per sub-step; round 2's band kernels:
+// 25.1).  With many fields it is bound by instruction issue (one vector instruction per SIMD every 4 cycles) and by how
+// evenly the SIMDs are loaded: step_rows_tasks below builds the launch order, ONE round of at most as many tasks as the
+// chip has wavefront slots.
 // STRICT keeps the reference's expression trees (bit-exact), FAST the re-associated ones of the other kernels.
 #include <algorithm>
 #include <cstring>

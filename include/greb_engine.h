@@ -206,7 +206,7 @@ int greb_release_caches(void);
  * tests check that every row of every field is written exactly once. */
 int greb_diffusion_launch_order(const greb_params* p, int nx, int ny, int batch, int* field, int* k0, int* k1, int* up,
                                 int capacity);
-/* The same for the engine's row-strip circulation sub-step (GREB_F_ROW_STRIPS): field = 2 * member + tracer; kappa:
+/* The same for the engine's row-strip circulation in its one-launch-per-sub-step form (384- and 192-wide grids): field = 2 * member + tracer; kappa:
  * [n_members] diffusivities (own sub-cycle tables) or NULL for p->kappa everywhere.  The order is the one an MI355X
  * (256 compute units) gets: at most one task per wavefront slot (2 048), tasks i and i + 1 024 share a SIMD. */
 int greb_substep_launch_order(const greb_params* p, int nx, int ny, int n_members, const float* kappa, int* field, int* k0,
