@@ -36,6 +36,9 @@
 !                        that all processes share one namelist file:   greb_host <namelist> <proc_id> <n_procs> [plan]   (or: greb_host <namelist> plan)
 !                        (`plan` prints the block and stops before any input is read or any GPU is touched).  With
 !                        &ENGINE_PAR device unset, process proc_id uses GPU proc_id.  tools/launch_ensemble.py starts them.
+! &ENGINE_PAR one_launch (384- / 192-wide grids): 1 = the circulation call as one launch (GREB_F_PERSISTENT), 0 = one launch
+!                        per sub-step (GREB_F_NO_PERSISTENT), unset = the engine times both and keeps the faster -- except
+!                        where several host processes were given the same device: there 0, see below.
 ! The interface module is host/greb_c_api.f90.
 
 program greb_host
@@ -67,8 +70,9 @@ program greb_host
   namelist / numerics_par / ipx, ipy, time_flux, time_scnr, year0
   namelist / diagnostics_par / output_file, ens_id
   namelist / co2_par / co2_ppm, co2_flux
-  integer :: chunk_years
-  namelist / engine_par / strict, device, corr_file, nx, ny, chunk_years
+  integer :: chunk_years, one_launch
+  logical :: device_given
+  namelist / engine_par / strict, device, corr_file, nx, ny, chunk_years, one_launch
   ! ---- ensemble
   integer :: n_members, n_total, n_procs, proc_id, first_member, gm
   logical :: plan_only
@@ -111,7 +115,7 @@ program greb_host
   co2_flux = prm%co2_flux
   ipx = 1; ipy = 1; time_flux = 0; time_scnr = 0; year0 = 1940
   output_file = 'output/scenario'; ens_id = ''
-  strict = .false.; device = -1; corr_file = ''; nx = 96; ny = 48; chunk_years = 0
+  strict = .false.; device = -1; corr_file = ''; nx = 96; ny = 48; chunk_years = 0; one_launch = -1
   n_members = 1; co2_lo = unset; co2_hi = unset; n_procs = 1; proc_id = 0; plan_only = .false.
   allocate(ens_ids(max_members), co2_levels(max_members), ens_da_ice(max_members), ens_a_no_ice(max_members), &
        ens_a_cloud(max_members), ens_kappa(max_members))
@@ -161,6 +165,7 @@ program greb_host
   first_member = proc_id*(n_total/n_procs) + min(proc_id, mod(n_total, n_procs)) + 1
   n_members = n_total/n_procs
   if (proc_id < mod(n_total, n_procs)) n_members = n_members + 1
+  device_given = device >= 0
   if (device < 0) device = merge(proc_id, 0, n_procs > 1)
   if (n_procs > 1) print '(a,i0,a,i0,a,i0,a,i0,a,i0,a,i0)', ' % ENSEMBLE BLOCK; process ', proc_id, ' of ', n_procs, &
        ': members ', first_member, ' .. ', first_member + n_members - 1, ' of ', n_total, ' on device ', device
@@ -260,6 +265,13 @@ program greb_host
   fld%mldclim = c_loc(mldclim); fld%cldclim = c_loc(cldclim); fld%swetclim = c_loc(swetclim)
   flags = 0
   if (strict) flags = 1
+  ! 384- / 192-wide grids: the circulation call as ONE launch waits inside the kernel for its own strips, which must all
+  ! be resident at once; engines of one process share the device through a ledger, PROCESSES do not see each other.  So
+  ! several host processes told to use the SAME device (&ENGINE_PAR device given with n_procs > 1) take one launch per
+  ! sub-step unless the namelist says otherwise; one process per GPU (the default placement) lets the engine choose.
+  if (one_launch < 0 .and. n_procs > 1 .and. device_given) one_launch = 0
+  if (one_launch == 0) flags = flags + 8    ! GREB_F_NO_PERSISTENT
+  if (one_launch > 0) flags = flags + 16    ! GREB_F_PERSISTENT
   eng = c_null_ptr
   if (own_physics) then
      rc = greb_engine_create(prm, int(nx, c_int), int(ny, c_int), fld, int(n_members, c_int), c_loc(ov), int(device, c_int), flags, eng)
