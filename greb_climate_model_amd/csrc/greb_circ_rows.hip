@@ -51,6 +51,9 @@ struct CircArgs {
   int n_tasks;
   int ny, nsub, calm_odd;  // calm_odd: the vapour fields see zero wind (greb.original.model.f90:560-564)
   int chains_first;        // who issues first where a chain and a streaming strip share a SIMD
+#ifdef GREB_TUNING
+  int lose_task;           // this task leaves at once and never publishes: the test of the bounded waits (-1: none)
+#endif
   int chain_head, chain_tail; // sweeps of a chain task's diffusion chain before it publishes the previous sub-step / after it polls
   unsigned long long* stamps;   // -DGREB_TUNING builds only: [s] = s_memrealtime at the start of sub-step s of task 0, [nsub] its end
   unsigned long long* timeline; // -DGREB_TUNING builds only: [task][start, end] + [2 n + task]: hw id
@@ -302,6 +305,9 @@ __global__ __launch_bounds__(64 * kTasksPerGroup, 2) void circ_rows_kernel(const
   extern __shared__ __align__(16) float lds_raw[];
   const int task = task_index();
   if (task >= a.n_tasks) return; // (the last workgroup of a launch whose task count is not a multiple of four)
+#ifdef GREB_TUNING
+  if (task == a.lose_task) return; // (tests/test_gpu_tools.py: its neighbours must give up after spin_ticks, not hang)
+#endif
   lfloat* lds = (lfloat*)lds_raw + (size_t)(task & (kTasksPerGroup - 1)) * (kStepLdsB / 4);
   const ctask& tk = *(const ctask*)(a.tasks + task); // eight dwords through the scalar cache
   int fld = tk.field;
@@ -518,6 +524,10 @@ hipError_t launch_circulation_rows(float* X0, float* X1, const float* W2, const 
   a.flags = order.flags; a.ctrl = order.ctrl; a.epoch0 = order.epoch; a.spin_ticks = kCircSpinTicks;
   a.n_tasks = order.n; a.ny = ny; a.nsub = nsub; a.calm_odd = calm_vapor ? 1 : 0; a.chains_first = chains_first ? 1 : 0;
   a.chain_head = head; a.chain_tail = tail;
+#ifdef GREB_TUNING
+  a.lose_task = tuning_int("GREB_CIRC_LOSE_TASK", -1);
+  if (const int spin_ms = tuning_int("GREB_CIRC_SPIN_MS", 0)) a.spin_ticks = (unsigned)spin_ms * 100000u; // a shorter bound for that test
+#endif
 #ifdef GREB_TUNING
   a.stamps = g_circ_stamps;
   a.timeline = order.n == g_circ_timeline_cap ? g_circ_timeline : nullptr;

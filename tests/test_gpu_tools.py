@@ -28,3 +28,39 @@ def test_workgroup_i_and_i_plus_n_simd_share_a_simd_on_an_idle_device():
     print(r.stdout)
     assert n_simd == 1024 and pairs > 900, (n_simd, pairs)      # an MI355X, and the 62-member launch fills its SIMDs in pairs
     assert hit >= 0.97 * pairs, f"only {hit} of {pairs} SIMD pairs are (i, i + {n_simd}): the dispatch order the launch orders assume does not hold"
+
+
+def test_a_circulation_launch_that_cannot_complete_is_an_error_not_a_hang():
+    """The one-launch circulation call (greb_circ_rows.hip) waits inside the kernel for its own tasks; every such wait is
+    bounded.  The tuning library can make one task leave without publishing (GREB_CIRC_LOSE_TASK) -- what a launch that is
+    not resident as a whole looks like to its neighbours -- with the bound shortened to 20 ms (GREB_CIRC_SPIN_MS): the run
+    must come back within seconds with GREB_E_STATE and the task and sub-step it gave up on, the abort must be sticky (the
+    year's remaining launches fall through), and the process must exit cleanly."""
+    from greb_climate_model_amd import build
+    if not os.path.exists(build.LIB_TUNING):
+        pytest.skip("no tuning library in this tree")
+    code = """
+import sys, time
+sys.path.insert(0, %r)
+from greb_climate_model_amd import engine, workload
+engine.use_tuning_build()
+inp = workload.make_inputs(384, 192)
+p = engine.params_default(); p.ipx, p.ipy = 380, 152
+e = engine.Engine(inp, p, n_members=2, persistent=True)
+t = time.perf_counter()
+try:
+    e.run(1, 680.0)
+    print("NO ERROR")
+except engine.GrebError as err:
+    print("ERROR", err.code, "|", err, "| %%.2f s" %% (time.perf_counter() - t))
+e.close()
+print("closed")
+""" % ROOT
+    env = dict(os.environ, GREB_CIRC_LOSE_TASK="5", GREB_CIRC_SPIN_MS="20")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "closed" in r.stdout, out[-2000:]
+    m = re.search(r"ERROR (-?\d+) \| (.*) \| ([0-9.]+) s", r.stdout)
+    assert m, out[-2000:]
+    assert int(m.group(1)) == -3 and "given up" in m.group(2) and "sub-step" in m.group(2), m.group(2)  # GREB_E_STATE
+    assert float(m.group(3)) < 30.0, m.group(3)  # one bounded wait + 729 launches that fall through, not 730 x 24 waits
