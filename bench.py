@@ -283,7 +283,9 @@ def main():
         if rank == 0:
             valid = gathered_valid(gathered[:, -1, :, 0].double().mean(dim=(1, 2)).cpu().numpy(), M, R)
             multi.update(ensemble.gather_order_check(valid, block=M if R == M else 0))
-    finite = bool(torch.isfinite(monthly if gathered is None else gathered).all().item())
+    # (rank 0 of an N > 1 run holds the gathered ensemble; the other ranks their own last year)
+    mine = monthly if world == 1 else (gathered if gathered is not None else year_bufs[-1][:my_m])
+    finite = bool(torch.isfinite(mine).all().item())
     tmean = float((monthly[:, -1, :, 0] if world == 1 else year_bufs[-1][:my_m, 0, :, 0]).mean().item())
 
     extra = {}
