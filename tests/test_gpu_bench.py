@@ -28,3 +28,26 @@ def test_two_ranks_on_one_card_over_gloo():
     assert set(pr) == {"integrate", "gather_wait", "total_before_barrier"}
     for v in pr.values():
         assert len(v["per_rank"]) == 2 and v["per_rank"][v["rank_of_max"]] == v["max"] >= v["min"] > 0
+
+
+@pytest.mark.parametrize("args", [["4", "--years", "2"], ["5", "--years", "1", "--members", "6"]])
+def test_run_config_as_two_ranks_on_one_card(args):
+    """tools/run_config.py 4 / 5 (BASELINE's 8-GPU configs) as the driver's launcher would start them -- torch.distributed.run,
+    one process per rank -- with two ranks sharing this card over gloo: members dealt to the ranks, each rank's engine(s),
+    the gather of the monthly means to rank 0.  (Two PROCESSES with one-launch circulation calls on one device: their
+    tasks together are far fewer than its wavefront slots.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GREB_BENCH_BACKEND="gloo", GREB_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "tools", "run_config.py"), *args], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    n = 8 if args[0] == "4" else 6
+    assert d["n_gpus"] == 2 and d["members_total"] == n and d["members_this_rank"] == n // 2 and d["finite"] is True
+    t = d["last_year_global_mean_tsurf_C"]
+    assert len(t) == n // 2 and all(-20.0 < x < 30.0 for x in t)
+    if args[0] == "4":
+        assert t == sorted(t) and t[-1] - t[0] > 1.0  # more CO2, warmer (this rank's block of the sweep)

@@ -36,10 +36,17 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs for a one-GPU box (N ranks sharing the card over gloo), as in bench.py; never set on a real node
+    backend = os.environ.get("GREB_BENCH_BACKEND", "nccl")
+    if "GREB_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["GREB_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = args.config
     g384 = cfg in (3, 5)
