@@ -264,7 +264,8 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
   CircOrder* circ = nullptr;
   if (rows && e->persistent && a.nsub > 0) {
     if (e->cus <= 0) HIP_TRY(e, hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, e->device));
-    if (e->slots_granted < 0) e->slots_granted = ledger_grant(e, e->cus * kStepRowsSlotsPerCu);
+    static const int slots_per_cu = tuning_int("GREB_CIRC_SLOTS_PER_CU", kStepRowsSlotsPerCu); // -DGREB_TUNING builds only (occupancy experiments: <= 8)
+    if (e->slots_granted < 0) e->slots_granted = ledger_grant(e, e->cus * std::min(slots_per_cu, kStepRowsSlotsPerCu));
     auto it = e->circ_orders.find(nrun);
     if (it == e->circ_orders.end()) {
       CircOrder o;
