@@ -298,7 +298,8 @@ int run_year(greb_engine* e, const MemberArgs& a, int nrun) {
       RowsTask* dev = nullptr; int n = 0;
       if (e->cus <= 0) HIP_TRY(e, hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, e->device));
       greb_engine::StepOrder so{};
-      HIP_TRY(e, step_rows_make_tasks(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, e->cus * kStepRowsSlotsPerCu, &dev, &n, so.head));
+      static const int step_slots = tuning_int("GREB_STEP_SLOTS_PER_CU", kStepRowsSlotsPerCu); // -DGREB_TUNING builds only (occupancy experiments)
+      HIP_TRY(e, step_rows_make_tasks(e->h_tabs.data(), e->h_tab_index.data(), nrun, e->ny, e->cus * step_slots, &dev, &n, so.head));
       so.dev = dev; so.n = n;
       it = e->step_tasks.emplace(nrun, so).first;
     }

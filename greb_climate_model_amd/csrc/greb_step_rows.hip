@@ -44,8 +44,18 @@ struct StepArgs {
   unsigned long long* stamps; // -DGREB_TUNING builds only (null otherwise): s_memtime stamps of task 0
   unsigned long long* timeline; // -DGREB_TUNING builds only: [task][start, end] in s_memrealtime ticks (100 MHz) + [2 n]: hw id
 };
+// (A/B of compile-time choices, tools/build_variant.sh: -DGREB_STEP_RING=3 -DGREB_STEP_WAVES=3: three landing slots and
+// 168 VGPRs, nine wavefronts per CU instead of eight)
+#ifndef GREB_STEP_RING
+#define GREB_STEP_RING 4
+#endif
+#ifndef GREB_STEP_WAVES
+#define GREB_STEP_WAVES 1
+#endif
+constexpr int kStepRing = GREB_STEP_RING;
+constexpr unsigned kStepRowsLdsB = kRowB + (kStepRing + 2) * kSlotB;
 template <bool STRICT, int NXR>
-__global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
+__global__ __launch_bounds__(64, GREB_STEP_WAVES) void step_rows_kernel(const StepArgs a) {
   extern __shared__ __align__(16) float lds_raw[];
   lfloat* lds = (lfloat*)lds_raw;
   // (field, rows) as ONE 8-byte scalar load issued with the argument loads: as two fields with a test between them the
@@ -83,7 +93,7 @@ __global__ __launch_bounds__(64) void step_rows_kernel(const StepArgs a) {
   if (a.stamps && blockIdx.x == 0) st.first = a.stamps;
   if (a.stamps && blockIdx.x == (gridDim.x * 3) / 4) st.phases = a.stamps; // a task three quarters down the launch order
 #endif
-  stream_strip<STRICT, kAuxPlain, false, NXR>(lds, io, tab, k0, k1, ny, a.calm_odd && tracer, a.chains_first, lane, st);
+  stream_strip<STRICT, kAuxPlain, false, NXR, kStepRing>(lds, io, tab, k0, k1, ny, a.calm_odd && tracer, a.chains_first, lane, st);
 #ifdef GREB_TUNING
   if (a.timeline && threadIdx.x == 0) a.timeline[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -221,7 +231,7 @@ hipError_t launch_substep_rows(const float* X, const float* W2, const float* u, 
 #endif
   auto kern = nx == kNx ? (strict ? step_rows_kernel<true, kNx> : step_rows_kernel<false, kNx>)
                         : (strict ? step_rows_kernel<true, kNx / 2> : step_rows_kernel<false, kNx / 2>);
-  hipLaunchKernelGGL(kern, dim3((unsigned)n_tasks), dim3(64), kStepLdsB, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_tasks), dim3(64), kStepRowsLdsB, s, a);
   return hipGetLastError();
 }
 

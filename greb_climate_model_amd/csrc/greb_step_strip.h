@@ -117,7 +117,7 @@ struct StripIo {
 
 // Rows [k0, k1) of one field, one sub-step.  On entry the wavefront has no vector-memory operation outstanding (vmcnt is
 // counted by hand from zero); on exit the stores of the last rows may still be in flight.
-template <bool STRICT, int AUX_X, bool SC1, int NXR = kNx>
+template <bool STRICT, int AUX_X, bool SC1, int NXR = kNx, int RING = kRing>
 __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, const crow_tables& tab, int k0, int k1, int ny,
                                              bool calm, int chains_first, unsigned lane, const StripStamps& st) {
   const float* Xf = io.Xf;
@@ -128,18 +128,21 @@ __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, con
   const unsigned lb = (unsigned)(size_t)lds;
   const bool last_lane = bug_lane<NXR>(lane);
   constexpr int kStores = NXR == kNx ? 2 : 1; // store instructions per row (store_row_quads)
+  static_assert(RING == 3 || RING == 4, "landing slots of the tracer / weight rows (gT holds four 16-bit counters)");
+  constexpr unsigned kWindAt = kRowB + RING * kSlotB; // (the wind ring follows the row ring)
+  auto ring_slot = [](int row) { return RING == 4 ? (row & 3) : row % 3; };
   if (!chains_first) __builtin_amdgcn_s_setprio(2); // streaming rows ahead of the chains (which drop to 0 while they sweep)
   int ops = 0;
   unsigned long long gT = 0, gU = 0; // 16 bits per slot: `ops` right after the slot's LDS-DMA was issued
   auto issue_T = [&](int row) {
-    const int slot = row & (kRing - 1);
+    const int slot = ring_slot(row);
     issue_pair_p<AUX_X>(PX, row * NXR, lds + (kRingBase + slot * kSlotB) / 4);
     ops += 3;
     gT = (gT & ~(0xffffull << (16 * slot))) | ((unsigned long long)ops << (16 * slot));
   };
   auto issue_U = [&](int row) {
     const int slot = row & 1;
-    issue_pair_p<kAuxPlain>(PU, row * NXR, lds + (kWindBase + slot * kSlotB) / 4);
+    issue_pair_p<kAuxPlain>(PU, row * NXR, lds + (kWindAt + slot * kSlotB) / 4);
     ops += 3;
     gU = (gU & ~(0xffffull << (16 * slot))) | ((unsigned long long)ops << (16 * slot));
   };
@@ -148,7 +151,7 @@ __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, con
   // slots (up to kRing - 1 rows are in flight ahead of the window), and the slot is refilled as soon as it is read.
   const int lo = k0 >= 2 ? k0 - 2 : 0, hi = k1 + 1 < ny ? k1 + 1 : ny - 1;
   int next_issue = lo;
-  for (int j = 0; j < kRing && next_issue <= hi; ++j) issue_T(next_issue++);
+  for (int j = 0; j < RING && next_issue <= hi; ++j) issue_T(next_issue++);
   issue_U(k0);
   float Tw[5][6], ww[5][6]; // rows c-2 .. c+2 of the tracer and its weight; a row outside the grid has weight zero
 #pragma unroll
@@ -160,9 +163,9 @@ __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, con
     const bool have = row >= lo && row <= hi;
     PairRaw raw;
     if (have) {
-      const int slot = row & (kRing - 1);
-      // (mid-strip the row was requested four steps ago: 2 + 3 x 8 + 3 operations since, at two stores per row)
-      wait_all_but_mostly<23 + 3 * kStores>(ops - (int)((gT >> (16 * slot)) & 0xffff));
+      const int slot = ring_slot(row);
+      // (mid-strip the row was requested RING steps ago: 2 + (RING - 1) x 8 + 3 operations since, at two stores per row)
+      wait_all_but_mostly<5 + (RING - 1) * (6 + kStores)>(ops - (int)((gT >> (16 * slot)) & 0xffff));
       read_pair_issue(L, lb + kRingBase + slot * kSlotB, raw); // ... and the window shifts under the LDS latency
     }
 #pragma unroll
@@ -197,7 +200,7 @@ __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, con
   float u[6], v[6];
   if (k0 + 1 < k1) issue_U(k0 + 1);
   wait_all_but(ops - (int)((gU >> (16 * (k0 & 1))) & 0xffff));
-  read_pair(L, lb + kWindBase + (k0 & 1) * kSlotB, u, v);
+  read_pair(L, lb + kWindAt + (k0 & 1) * kSlotB, u, v);
   for (int r = k0; r < k1; ++r) {
     GREB_STEP_STAMP(0);
     GREB_STEP_PHASE(0);
@@ -262,7 +265,7 @@ __device__ __forceinline__ void stream_strip(lfloat* lds, const StripIo& io, con
     GREB_STEP_PHASE(3);
     if (r + 1 < k1) { // the next row's winds (requested at the start of the previous step: 13 operations since, mid-strip)
       wait_all_but_mostly<11 + kStores>(ops - (int)((gU >> (16 * ((r + 1) & 1))) & 0xffff));
-      read_pair(L, lb + kWindBase + ((r + 1) & 1) * kSlotB, u, v);
+      read_pair(L, lb + kWindAt + ((r + 1) & 1) * kSlotB, u, v);
     }
     GREB_STEP_PHASE(4);
   }

@@ -9,7 +9,7 @@ C=greb_climate_model_amd/csrc
 objs=""
 for s in greb_engine.cpp greb_kernels.hip greb_member.hip greb_ensemble.hip greb_rows.hip greb_step_rows.hip greb_circ_rows.hip; do
   o=$C/_obj/${s%.*}_tuning.o
-  case $s in greb_rows.hip)
+  case $s in greb_rows.hip|greb_step_rows.hip)
     o=variants/${s%.*}_$tag.o
     hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wno-unused-value -Iinclude -DGREB_TUNING -fno-slp-vectorize "$@" -c $C/$s -o $o;;
   esac
