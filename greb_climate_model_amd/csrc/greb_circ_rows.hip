@@ -422,6 +422,14 @@ void circ_rows_tasks(const RowTables* tabs, const int* tab_index, int n_members,
       order[(size_t)(n_simd + j)] = all[(size_t)(n_all - 1 - j)]; // ... and the cheapest left
     }
     for (int j = 0; j < alone; ++j) order[(size_t)(m + j)] = all[(size_t)j];
+    // ... as the hardware deals them: the wavefronts of the SECOND workgroup on a compute unit start one SIMD further on
+    // (observed, tools/circ_timeline.py: second-round wavefront w sits on SIMD (w + 1) mod 4, so task i shares its SIMD
+    // with task i + 1 023 or i + 1 027, never i + 1 024): the partner meant for SIMD w goes to wavefront (w + 3) mod 4
+    for (int c = 0; n_simd + 4 * c + 3 < n_all; ++c) {
+      const size_t b = (size_t)n_simd + 4 * (size_t)c;
+      const T t0 = order[b], t1 = order[b + 1], t2 = order[b + 2], t3 = order[b + 3];
+      order[b + 3] = t0; order[b] = t1; order[b + 1] = t2; order[b + 2] = t3;
+    }
     all.swap(order);
   }
   // who owns which row of which field

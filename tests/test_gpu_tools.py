@@ -64,3 +64,23 @@ print("closed")
     assert m, out[-2000:]
     assert int(m.group(1)) == -3 and "given up" in m.group(2) and "sub-step" in m.group(2), m.group(2)  # GREB_E_STATE
     assert float(m.group(3)) < 30.0, m.group(3)  # one bounded wait + 729 launches that fall through, not 730 x 24 waits
+
+
+def test_the_one_launch_circulation_pairs_the_tasks_its_order_means_to_pair():
+    """circ_rows_tasks pairs the two tasks of a SIMD ("dearest with cheapest").  The one-launch kernel runs four tasks per
+    workgroup, one per SIMD of the workgroup's compute unit; what was OBSERVED and is relied on for speed only: the second
+    workgroup on a compute unit starts one SIMD further on, so task 4c + w shares its SIMD with task n_simd + 4c + (w + 3)
+    mod 4 -- the order is built for exactly that.  Read from HW_REG_HW_ID / XCC_ID per task (tools/circ_timeline.py)."""
+    from greb_climate_model_amd import build
+    if not os.path.exists(build.LIB_TUNING):
+        pytest.skip("no tuning library in this tree")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "circ_timeline.py"), "62", "8"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    print(r.stdout)
+    m = re.search(r"PREMISE task 4c \+ w shares its SIMD with task (\d+) \+ 4c \+ \(w \+ 3\) mod 4: (\d+) of (\d+) SIMDs", r.stdout)
+    g = re.search(r"workgroups whose four tasks sit on the four SIMDs of one CU: (\d+) of (\d+)", r.stdout)
+    assert m and g, r.stdout[-2000:]
+    n_simd, hit, pairs = map(int, m.groups())
+    assert n_simd == 1024 and pairs > 900 and hit >= 0.97 * pairs, (n_simd, hit, pairs)
+    assert int(g.group(1)) >= 0.97 * int(g.group(2)), g.groups()

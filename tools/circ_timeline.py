@@ -65,6 +65,15 @@ kinds = {}
 for v in pairs.values():
     kk = tuple(sorted(("C" if chain[j] and k0[j] in (1, 190) else ("c" if chain[j] else "s")) for j in v))
     kinds.setdefault(kk, []).append(v)
+both = [v for v in pairs.values() if len(v) == 2]
+dist = np.array([abs(v[0] - v[1]) for v in both]) if both else np.zeros(0, int)
+vals, cnts = np.unique(dist, return_counts=True)
+n_simd = len(u) if len(u) >= 1024 else 1024
+meant = sum(1 for v in both if max(v) == n_simd + 4 * (min(v) // 4) + (min(v) % 4 + 3) % 4)
+print(f"PREMISE task 4c + w shares its SIMD with task {n_simd} + 4c + (w + 3) mod 4: {meant} of {len(both)} SIMDs that hold two tasks; "
+      "index distances (distance: count): " + " ".join(f"{a}:{b}" for a, b in sorted(zip(vals, cnts), key=lambda x: -x[1])[:6]))
+same_cu = sum(1 for j in range(0, n - n % 4, 4) if len({key[j + q] // 4 for q in range(4)}) == 1 and len({key[j + q] % 4 for q in range(4)}) == 4)
+print(f"workgroups whose four tasks sit on the four SIMDs of one CU: {same_cu} of {n // 4}")
 print("(for chain tasks 'draining' is the time in the zonal chains, their publish included)")
 print("what shares a SIMD (C: chain task rows 1/190, c: other chain task, s: strip): mean wait per sub-step of its tasks")
 for kk, vs in sorted(kinds.items()):
