@@ -39,7 +39,7 @@ def test_run_config_as_two_ranks_on_one_card(args):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(GREB_BENCH_BACKEND="gloo", GREB_BENCH_DEVICE="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(ROOT, "tools", "run_config.py"), *args], env=env, capture_output=True,
+                        "--master-port", str(29541 + 2 * int(args[0])), os.path.join(ROOT, "tools", "run_config.py"), *args], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
