@@ -724,3 +724,27 @@ def test_engine_g192_vs_reference(eng_mod, oracle_lib):
                  ("fast strips, one launch per call", "fast strips, one launch per sub-step")):
         for x, y in zip(runs[a], runs[b]):
             assert np.array_equal(x, y), (a, b)  # the same arithmetic through different data movement: bit for bit
+
+
+def test_engine_g192_members_are_independent(eng_mod):
+    """192x96 on the native strips with several members in one engine (tasks share SIMDs from 10 members on): a member's
+    result must not depend on who else is in the engine -- member k of a 24-member CO2 sweep equals the same member run
+    alone, bit for bit (members are separate processes in the reference, src/greb.f90:153,1064-1068) --, replicas agree,
+    and more CO2 is warmer."""
+    from greb_climate_model_amd import abi, ensemble, workload
+    inp = workload.make_inputs(192, 96)
+    p = abi.default_params(ipx=190, ipy=75)
+    levels = ensemble.co2_sweep(24).astype(np.float32)
+    levels[23] = levels[5]  # a replica
+    e = eng_mod.Engine(inp, p, n_members=24)
+    e.flux_correction(1)
+    mon, yr = e.run(1, levels[:, None])
+    e.close()
+    assert np.isfinite(mon).all() and np.array_equal(mon[23], mon[5])
+    t = yr[:23, -1, 0]
+    assert (np.diff(t) > 0).all(), t
+    one = eng_mod.Engine(inp, p, n_members=1)
+    one.flux_correction(1)
+    m1, y1 = one.run(1, levels[7:8, None])
+    one.close()
+    assert np.array_equal(m1[0], mon[7]) and np.array_equal(y1[0], yr[7])
